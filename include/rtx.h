@@ -1,0 +1,303 @@
+/*
+ * rtx.h — C ABI of the MI355X-native ray-casting / light-transport path.
+ *
+ * This is the drop-in boundary for the hot path of DHRRAM/RayTracer. The reference has no FFI layer of its
+ * own (it is one C++ executable); each entry point below names the in-process C++ interface it replaces
+ * (paths relative to the reference repository). The C++ host mirror in raytracer_amd/host/ keeps the
+ * reference's class and function names (RayCaster, IntersectNode, IntersectSceneWithLights,
+ * CollectSceneNodeObjects, ShadeInfoAdapter, PhotonMapBuilder) and forwards to these functions.
+ *
+ * Conventions
+ *  - Only POD structs and C types cross the boundary. Status 0 = ok, negative = error; the message is
+ *    available from rtx_last_error() (thread-local).
+ *  - Host pointers in descriptors are caller-owned and copied before the call returns.
+ *  - Handles own device memory. One in-flight call per handle; different handles may be used from different
+ *    threads.
+ *  - There is no CPU fallback: every compute entry point fails with RTX_ERR_NO_DEVICE when no HIP device is
+ *    present.
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- constants (framework conventions used by the reference's hot path) ------------------------------- */
+#define RTX_HIT_NONE 0
+#define RTX_HIT_FRONT 1            /* IntersectNodeAdapter.h:100 default hitSide                            */
+#define RTX_HIT_BACK 2
+#define RTX_HIT_FRONT_AND_BACK 3   /* RayCaster.cpp:361 (path loop), RayCaster.h:82                          */
+#define RTX_BIGFLOAT 1.0e30f       /* framework BIGFLOAT (stand-in choice)                   */
+
+#define RTX_OK 0
+#define RTX_ERR_INVALID (-1)
+#define RTX_ERR_NO_DEVICE (-2)
+#define RTX_ERR_HIP (-3)
+#define RTX_ERR_TOO_LARGE (-4)
+
+#define RTX_MAX_LIGHTS 8
+
+#define RTX_MTL_BLINN 0            /* Shading.cpp:715-725 */
+#define RTX_MTL_PHONG 1            /* Shading.cpp:727-737 */
+
+#define RTX_TEX_RGB8 0             /* Color24 texels (PNG)            */
+#define RTX_TEX_RGB32F 1           /* float texels (Radiance HDR)     */
+
+#define RTX_FILTER_TENT 0          /* RayCaster.h:23, RayCaster.cpp:643-690 */
+#define RTX_FILTER_GAUSSIAN 1
+#define RTX_FILTER_MITCHELL 2
+#define RTX_FILTER_LANCZOS 3
+
+typedef struct rtx_scene rtx_scene;   /* opaque: flattened BVH + triangles + materials + lights in HBM */
+typedef struct rtx_photons rtx_photons; /* opaque: photon maps + hash grids in HBM                      */
+
+/* ---- scene description -------------------------------------------------------------------------------- */
+
+/* One (Node, TriObj) pair as produced by CollectSceneNodeObjects (SceneAdapter.h:8-18). Index triplets and
+ * vertex arrays follow cy::TriMesh (V/VN/VT, F/FN/FT). vn/fn and vt/ft may be NULL (objects.cpp:181,202). */
+typedef struct {
+    const float* v;   int nv;      /* xyz                                                    */
+    const float* vn;  int nvn;     /* xyz, optional                                          */
+    const float* vt;  int nvt;     /* uvw, optional                                          */
+    const int* f;                  /* 3*nf vertex indices                                    */
+    const int* fn;                 /* 3*nf normal indices, optional (NULL: same as f)        */
+    const int* ft;                 /* 3*nf texcoord indices, optional (NULL: same as f)      */
+    const int* face_mtl;           /* nf per-face GetMaterialIndex, optional (objects.cpp:236) */
+    int nf;
+    float xform[12];               /* object->world 3x4 row-major (accumulated Node transforms; identity for
+                                      every object of assets/cerealBar.xml:5-51)             */
+    int material;                  /* index into rtx_scene_desc.materials; -1 = none         */
+} rtx_mesh_desc;
+
+/* Texture image + TextureMap transform (texture-space matrix applied to uvw before lookup). */
+typedef struct {
+    int format;                    /* RTX_TEX_*            */
+    int width, height;
+    const void* texels;            /* width*height*3 u8 or float, row 0 first */
+    float xform[12];               /* uvw' = M * (uvw,1), 3x4 row-major       */
+} rtx_texmap_desc;
+
+/* MtlBlinn / MtlPhong parameters (framework MtlBasePhongBlinn; Shading.cpp:227-278).
+ * *_tex = index into texmaps or -1. The TexturedColor value multiplies the texture. */
+typedef struct {
+    int type;                      /* RTX_MTL_*                                     */
+    float diffuse[3];    int diffuse_tex;
+    float specular[3];   int specular_tex;
+    float reflection[3]; int reflection_tex;
+    float refraction[3]; int refraction_tex;
+    float emission[3];   int emission_tex;
+    float glossiness;
+    float ior;
+    float absorption[3];           /* Beer-Lambert coefficients, RayCaster.cpp:281-301 */
+    int bump_tex;                  /* BumpMapping.h:19, -1 = none                    */
+    float bump_scale;              /* BumpMapping.h:60                               */
+} rtx_material_desc;
+
+/* PointLight (Shading.cpp:65-209): size > 0 is a renderable sphere light. */
+typedef struct {
+    float position[3];
+    float intensity[3];
+    float size;
+    float attenuation;
+} rtx_light_desc;
+
+typedef struct {
+    const rtx_mesh_desc* meshes;        int n_meshes;
+    const rtx_material_desc* materials; int n_materials;
+    const rtx_texmap_desc* texmaps;     int n_texmaps;
+    const rtx_light_desc* lights;       int n_lights;
+    float environment[3]; int environment_tex;   /* Scene::environment (RayCaster.cpp:368-370) */
+    float background[3];  int background_tex;    /* Scene::background  (RayCaster.cpp:367-369) */
+    float background_emission;                   /* Scene::backgroundEmission (:371)            */
+} rtx_scene_desc;
+
+/* Camera (framework Camera; RayCaster.cpp:717-762, CameraAdapter.h:7-27). dir need not be unit length. */
+typedef struct {
+    float pos[3], dir[3], up[3];
+    float fov;                     /* degrees, vertical */
+    float focaldist, dof;
+    int width, height;
+    int srgb;
+} rtx_camera;
+
+/* ---- rays and hits ------------------------------------------------------------------------------------ */
+typedef struct {
+    float o[3];
+    float tmax;                    /* in: HitInfo::z upper bound (IntersectNodeAdapter.h:28,103) */
+    float d[3];
+    float pad;
+} rtx_ray;
+
+/* The fields of the framework HitInfo that the hot path reads. */
+typedef struct {
+    float t;                       /* HitInfo::z; RTX_BIGFLOAT... unchanged tmax when no hit          */
+    int   obj;                     /* index of the (Node,Object) pair, -1 = no hit or light           */
+    int   face;                    /* faceID inside that object, -1 = none                            */
+    int   mtl_id;                  /* HitInfo::mtlID                                                   */
+    float p[3], N[3], GN[3];
+    float uvw[3];
+    float dpdu[3], dpdv[3];
+    float bu, bv;                  /* Moller-Trumbore u,v (objects.cpp:162,166)                       */
+    int   front;
+    int   light;                   /* index of the hit light (ExtendedHitInfo::hitLight) or -1        */
+} rtx_hit;
+
+/* ---- rendering ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int spp_min;                   /* kMinSamples/kInitSamples (RayCaster.cpp:51-52)                   */
+    int spp_max;                   /* kMaxSamples (:53); == spp_min renders a fixed sample count       */
+    int index_stride;              /* the 1024 of sampleIndex=(y*W+x)*kMaxSamples+(s+1) (:784); 0 -> 1024 */
+    float ci_halfwidth;            /* kMaxHalfWidth (:55)                                              */
+    int filter_type;               /* g_filterType (:30)                                               */
+    float filter_radius;           /* g_filterRadius (:31); <= 0 selects FilterDefaultSupport          */
+    int max_bounces;               /* 64 in RayCaster.cpp:358; 1 = direct lighting only (config C2)    */
+    uint64_t seed;                 /* counter-based RNG key                      */
+    int tile_size;                 /* bucket edge (RayCaster.cpp:1152), 0 -> 16                        */
+    int rank, world;               /* tile sharding: this call renders tiles t with t % world == rank  */
+    int samples_per_pass;          /* path-pool sizing: samples per pixel traced per wavefront pass; 0 = auto */
+    int use_photons;               /* gather the caustics map when a photon handle is given           */
+} rtx_render_params;
+
+/* Film accumulators, caller-provided DEVICE memory, all width*height, row-major y*W+x
+ * (per-thread buffers of RayCaster.cpp:1168-1171). The caller zeroes accum/count and fills z with
+ * RTX_BIGFLOAT (rtx_film_clear does this). Multi-GPU callers sum-reduce accum/count and min-reduce z
+ * across ranks (RayCaster.cpp:1182-1212) before rtx_film_resolve. */
+typedef struct {
+    float* accum;                  /* float4 per pixel: sum(w*r), sum(w*g), sum(w*b), sum(w)          */
+    int*   count;                  /* originSampleCount                                                */
+    float* z;                      /* accumZ                                                           */
+    float* albedo;                 /* float4 per pixel (first-hit albedo, w=written), optional NULL    */
+    float* normal;                 /* float4 per pixel, optional NULL                                  */
+} rtx_film;
+
+typedef struct {
+    uint64_t rays_primary;
+    uint64_t rays_bounce;
+    uint64_t rays_shadow;          /* shadow hops (each a closest-hit traversal, RayCaster.cpp:204-274) */
+    uint64_t rays_photon;
+    uint64_t paths;
+    uint64_t nodes_visited;        /* only filled when counters are enabled (rtx_set_counters)         */
+    uint64_t tris_tested;
+    double   extend_ms;            /* HIP-event time of the extend kernels in the last call             */
+    double   shadow_ms;
+    double   shade_ms;
+    double   total_ms;
+    uint64_t extend_launches;
+} rtx_stats;
+
+/* Photon mapping (PhotonMapBuilder.h:46-54). */
+typedef struct {
+    int num_photons;               /* emitted                                                           */
+    int max_bounces;               /* 2                                                                 */
+    float photon_radius;           /* <= 0: AdjustPhotonGatherSettings (PhotonMapBuilder.cpp:62-78)     */
+    float caustic_radius;          /* <= 0: derived                                                     */
+    int search_count;              /* 100                                                               */
+    uint64_t seed;
+    int first_photon, photon_stride; /* multi-GPU split: ids first, first+stride, ... (0,1 = all)       */
+} rtx_photon_params;
+
+/* One stored photon: position, direction of travel, power (cyPhotonMap record). */
+typedef struct {
+    float pos[3];
+    float dir[3];
+    float power[3];
+} rtx_photon;
+
+/* ---- entry points ------------------------------------------------------------------------------------- */
+
+/* Number of HIP devices visible (0 when none). */
+int rtx_device_count(void);
+
+/* Selects the HIP device for subsequent calls of this thread (one process per GPU: LOCAL_RANK). */
+int rtx_set_device(int device);
+
+const char* rtx_last_error(void);
+
+/* Library version string and build architecture ("gfx950"). */
+const char* rtx_version(void);
+
+/* Replaces: Renderer::LoadScene -> TriObj::BuildAcceleration (objects.cpp:128-138, bvh.SetMesh(this,4)) and
+ * the scene flattening hook CollectSceneNodeObjects (SceneAdapter.h:8-18). Builds the flattened wide BVH and
+ * the compact triangle streams on the host and uploads them. */
+int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out);
+void rtx_scene_destroy(rtx_scene* scene);
+
+/* Scene facts: counts[0]=triangles, [1]=BVH nodes, [2]=node bytes, [3]=triangle record bytes,
+ * [4]=device bytes total, [5]=BVH depth. bounds = child-union box of the root (Node::GetChildBoundBox). */
+int rtx_scene_info(const rtx_scene* scene, uint64_t counts[6], float bounds[6]);
+
+/* Replaces: IntersectNode(&scene->rootNode, ray, hit, hitSide) (IntersectNodeAdapter.h:100-108) for a batch
+ * of rays; with with_lights != 0 it is IntersectSceneWithLights (IntersectNodeAdapter.h:111-151).
+ * rays/hits are HOST arrays of n elements. */
+int rtx_trace_closest(rtx_scene* scene, const rtx_ray* rays, size_t n, int hit_side, int with_lights,
+                      rtx_hit* hits);
+
+/* Same, DEVICE pointers, compact result only: hit4[i] = {t, u, v, bits(prim)}; prim = global triangle index
+ * (object order, then face order), -1 = miss, -2-k = light k. stream is a hipStream_t or NULL. Used by the
+ * throughput benchmark and by callers that keep rays resident in HBM. */
+int rtx_trace_closest_device(rtx_scene* scene, const void* rays_dev, size_t n, int hit_side, int with_lights,
+                             void* hit4_dev, void* stream);
+
+/* Replaces: RayCastRenderer::TraceShadowRay (RayCaster.cpp:1412-1422) / Visible() (RayCaster.cpp:178-278):
+ * vis[i] in [0,1] for segment origin o, unit direction d, length tmax; use_transmittance selects the
+ * 8-hop Fresnel chain (:199-277) or the boolean test (:178-190). Host arrays. */
+int rtx_trace_visibility(rtx_scene* scene, const rtx_ray* rays, const float* normals, size_t n,
+                         int use_transmittance, float* vis);
+
+/* Replaces: GenerateCameraRay (CameraAdapter.h:7-27) + IntersectNode per pixel (config C1): fills host
+ * arrays face[W*H] (global triangle index or -1), t[W*H], front[W*H] (may be NULL). */
+int rtx_render_primary(rtx_scene* scene, const rtx_camera* cam, int hit_side, int* prim, float* t,
+                       unsigned char* front);
+
+/* Film helpers (device memory). */
+int rtx_film_clear(const rtx_film* film, int width, int height, void* stream);
+
+/* Replaces: RayCaster::CastRays (RayCaster.cpp:1146-1314) minus the merge: traces all samples of the tiles
+ * owned by params->rank and accumulates into film (device). photons may be NULL. Blocking. */
+int rtx_render_accumulate(rtx_scene* scene, const rtx_camera* cam, const rtx_render_params* params,
+                          rtx_photons* photons, const rtx_film* film, rtx_stats* stats);
+
+/* Replaces: mergeToImage (RayCaster.cpp:1182-1212) + ToColor24 (:33-48): final = sum/weight, 8-bit
+ * quantisation. Outputs are HOST arrays (any may be NULL): linear float3, rgb8, z, samples. */
+int rtx_film_resolve(const rtx_film* film, const rtx_camera* cam, float* linear_rgb, unsigned char* rgb8,
+                     float* z, int* samples, float* albedo, float* normal);
+
+/* Convenience single-GPU CastRays: clear + accumulate + resolve. */
+int rtx_render(rtx_scene* scene, const rtx_camera* cam, const rtx_render_params* params, rtx_photons* photons,
+               float* linear_rgb, unsigned char* rgb8, float* z, int* samples, rtx_stats* stats);
+
+/* Replaces: PhotonMapBuilder::BuildPhotonMap (PhotonMapBuilder.cpp:20-60): emission + tracing on the GPU.
+ * The stored photons stay in HBM inside the handle. */
+int rtx_photon_build(rtx_scene* scene, const rtx_photon_params* params, rtx_photons** out, rtx_stats* stats);
+void rtx_photons_destroy(rtx_photons* p);
+
+/* counts[0]=global photons stored, [1]=caustic photons stored; radii[0]=photon radius, [1]=caustic radius. */
+int rtx_photon_info(const rtx_photons* p, uint64_t counts[2], float radii[2]);
+
+/* Copies stored photon records (unscaled powers, emission order not guaranteed) to host. which: 0 global,
+ * 1 caustic. Returns number copied or negative error. */
+int64_t rtx_photon_download(const rtx_photons* p, int which, rtx_photon* out, size_t capacity);
+
+/* Multi-GPU: replace the caustic/global photon set with the concatenation gathered from all ranks (device
+ * pointer to n records) and rebuild the hash grid + power scaling (PhotonMapBuilder.cpp:38-50). */
+int rtx_photon_set(rtx_photons* p, int which, const void* photons_dev, size_t n, int total_emitted);
+
+/* Device address of the stored records (for RCCL all-gather by the caller). */
+void* rtx_photon_device_ptr(const rtx_photons* p, int which);
+
+/* Replaces: EstimateCaustics / PhotonMap::EstimateIrradiance<N,LINEAR> (RayCaster.cpp:143-153) for host
+ * probe points: irradiance rgb per probe. */
+int rtx_photon_estimate(rtx_photons* p, int which, const float* positions, const float* normals, size_t n,
+                        float* irradiance);
+
+/* Enables per-ray node/triangle counters (instrumented traversal; slower). */
+int rtx_set_counters(rtx_scene* scene, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H */

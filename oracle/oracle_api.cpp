@@ -1,0 +1,281 @@
+// TEST INFRASTRUCTURE ONLY (see oracle_math.h). C entry points of the CPU restatement, loaded with ctypes by
+// tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by the product.
+#include "oracle_shade.h"
+#include <cstring>
+#include <chrono>
+
+using namespace orc;
+
+static void fill_hit(const Scene& sc, const Hit& h, bool hit, float tmaxIn, rtx_hit* o) {
+    std::memset(o, 0, sizeof(*o));
+    o->t = hit ? h.z : tmaxIn;
+    o->obj = hit ? h.obj : -1;
+    o->face = hit ? h.face : -1;
+    o->mtl_id = hit ? h.mtlID : 0;
+    o->light = hit ? h.lightIdx : -1;
+    o->front = hit ? (h.front ? 1 : 0) : 1;
+    if (!hit) return;
+    const V3* src[6] = {&h.p, &h.N, &h.GN, &h.uvw, &h.dpdu, &h.dpdv};
+    float* dst[6] = {o->p, o->N, o->GN, o->uvw, o->dpdu, o->dpdv};
+    for (int k = 0; k < 6; ++k) {
+        dst[k][0] = src[k]->x;
+        dst[k][1] = src[k]->y;
+        dst[k][2] = src[k]->z;
+    }
+    o->bu = h.bu;
+    o->bv = h.bv;
+}
+
+extern "C" {
+
+int orc_scene_create(const rtx_scene_desc* d, void** out) {
+    *out = scene_from_desc(d);
+    return 0;
+}
+void orc_scene_destroy(void* s) { delete (Scene*)s; }
+
+int orc_scene_bounds(void* s, float b[6]) {
+    Scene* sc = (Scene*)s;
+    b[0] = sc->rootBox.pmin.x; b[1] = sc->rootBox.pmin.y; b[2] = sc->rootBox.pmin.z;
+    b[3] = sc->rootBox.pmax.x; b[4] = sc->rootBox.pmax.y; b[5] = sc->rootBox.pmax.z;
+    return 0;
+}
+
+// scene_box.cpp KAT: boxes[n][6], rays[n] (tmax in ray.tmax) -> out[n]
+int orc_box_intersect(const float* boxes, const rtx_ray* rays, size_t n, unsigned char* out) {
+    for (size_t i = 0; i < n; ++i) {
+        Box b;
+        b.pmin = V3(boxes[6 * i], boxes[6 * i + 1], boxes[6 * i + 2]);
+        b.pmax = V3(boxes[6 * i + 3], boxes[6 * i + 4], boxes[6 * i + 5]);
+        Ray r{V3(rays[i].o[0], rays[i].o[1], rays[i].o[2]), V3(rays[i].d[0], rays[i].d[1], rays[i].d[2])};
+        out[i] = b.intersect(r, rays[i].tmax) ? 1 : 0;
+    }
+    return 0;
+}
+
+// use_bvh: 1 = TraceBVHNode path, 0 = the reference's brute-force fallback (objects.cpp:256-265)
+int orc_trace_closest(void* s, const rtx_ray* rays, size_t n, int hit_side, int with_lights, int use_bvh,
+                      rtx_hit* hits, uint64_t* counters) {
+    Scene* sc = (Scene*)s;
+    for (size_t i = 0; i < n; ++i) {
+        Ray r{V3(rays[i].o[0], rays[i].o[1], rays[i].o[2]), V3(rays[i].d[0], rays[i].d[1], rays[i].d[2])};
+        Hit h;
+        h.init();
+        h.z = rays[i].tmax;
+        bool hit = with_lights ? sc->intersect_with_lights(r, h, hit_side, use_bvh != 0, counters)
+                               : sc->intersect_node(r, h, hit_side, use_bvh != 0, counters);
+        fill_hit(*sc, h, hit, rays[i].tmax, &hits[i]);
+    }
+    return 0;
+}
+
+int orc_trace_visibility(void* s, const rtx_ray* rays, const float* normals, size_t n, int use_transmittance, float* vis) {
+    Scene* sc = (Scene*)s;
+    for (size_t i = 0; i < n; ++i) {
+        V3 o(rays[i].o[0], rays[i].o[1], rays[i].o[2]), d(rays[i].d[0], rays[i].d[1], rays[i].d[2]);
+        V3 nn(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]);
+        vis[i] = visible(*sc, o, nn, d, rays[i].tmax, use_transmittance != 0, nullptr);
+    }
+    return 0;
+}
+
+// config C1: GenerateCameraRay + IntersectNode per pixel. prim = global triangle index (faceBase[obj]+face).
+int orc_render_primary(void* s, const rtx_camera* cam, int hit_side, int use_bvh, int* prim, float* t,
+                       unsigned char* front, uint64_t* counters) {
+    Scene* sc = (Scene*)s;
+    Camera c = camera_from(cam);
+    for (int y = 0; y < c.H; ++y)
+        for (int x = 0; x < c.W; ++x) {
+            Ray r = generate_camera_ray(c, x, y);
+            Hit h;
+            h.init();
+            bool hit = sc->intersect_node(r, h, hit_side, use_bvh != 0, counters);
+            size_t i = (size_t)y * c.W + x;
+            prim[i] = hit ? sc->faceBase[h.obj] + h.face : -1;
+            t[i] = hit ? h.z : BIGFLOAT;
+            if (front) front[i] = hit ? (h.front ? 1 : 0) : 1;
+        }
+    return 0;
+}
+
+// sampler KATs
+float orc_halton(int index, int base) { return halton(index, base); }
+void orc_pixel_shifts(int x, int y, float* sx, float* sy) { pixel_shifts(x, y, *sx, *sy); }
+float orc_rnd(uint64_t seed, uint32_t a, uint32_t b, uint32_t stream, uint32_t dim) { return rnd01(seed, a, b, stream, dim); }
+float orc_filter1d(int type, float radius, float x) { return filter1d(type, radius, x); }
+void orc_to_color24(const float* c, int srgb, unsigned char* out) { to_color24(V3(c[0], c[1], c[2]), srgb != 0, out); }
+// ray of sample s of pixel (x,y): RayCaster.cpp:784-796
+void orc_sample_ray(const rtx_camera* cam, int x, int y, int s, int index_stride, rtx_ray* out, float* samplePos) {
+    Camera c = camera_from(cam);
+    float shx, shy;
+    pixel_shifts(x, y, shx, shy);
+    int stride = index_stride > 0 ? index_stride : 1024;
+    int sampleIndex = (y * c.W + x) * stride + (s + 1);
+    float jx = std::fmod(halton(sampleIndex, 2) + shx, 1.0f) - 0.5f;
+    float jy = std::fmod(halton(sampleIndex, 3) + shy, 1.0f) - 0.5f;
+    float px = float(x) + 0.5f + jx, py = float(y) + 0.5f + jy;
+    Ray r = generate_ray(c, px, py, sampleIndex);
+    out->o[0] = r.p.x; out->o[1] = r.p.y; out->o[2] = r.p.z;
+    out->d[0] = r.dir.x; out->d[1] = r.dir.y; out->d[2] = r.dir.z;
+    out->tmax = BIGFLOAT;
+    out->pad = 0;
+    samplePos[0] = px;
+    samplePos[1] = py;
+}
+
+// BSDF KAT: context = P(3) V(3) N(3) GN(3) uvw(3) front ; key = (a,b,stream). out = dir(3) mult(3) prob dist lobe ok
+int orc_bsdf_sample(void* s, int material, const float* ctx, uint64_t seed, uint32_t a, uint32_t b, uint32_t stream,
+                    float* out) {
+    Scene* sc = (Scene*)s;
+    SInfo si;
+    si.P = V3(ctx[0], ctx[1], ctx[2]);
+    si.V = V3(ctx[3], ctx[4], ctx[5]);
+    si.N = V3(ctx[6], ctx[7], ctx[8]);
+    si.GN = V3(ctx[9], ctx[10], ctx[11]);
+    si.uvw = V3(ctx[12], ctx[13], ctx[14]);
+    si.front = ctx[15] != 0.0f;
+    si.seed = seed; si.ka = a; si.kb = b; si.stream = stream;
+    V3 dir;
+    DirInfo di;
+    bool ok = mtl_generate_sample(*sc, sc->materials[material], si, dir, di);
+    out[0] = dir.x; out[1] = dir.y; out[2] = dir.z;
+    out[3] = di.mult.x; out[4] = di.mult.y; out[5] = di.mult.z;
+    out[6] = di.prob; out[7] = di.dist; out[8] = (float)di.lobe; out[9] = ok ? 1.0f : 0.0f;
+    return 0;
+}
+int orc_bsdf_eval(void* s, int material, const float* ctx, const float* dirIn, float* out) {
+    Scene* sc = (Scene*)s;
+    SInfo si;
+    si.P = V3(ctx[0], ctx[1], ctx[2]);
+    si.V = V3(ctx[3], ctx[4], ctx[5]);
+    si.N = V3(ctx[6], ctx[7], ctx[8]);
+    si.GN = V3(ctx[9], ctx[10], ctx[11]);
+    si.uvw = V3(ctx[12], ctx[13], ctx[14]);
+    si.front = ctx[15] != 0.0f;
+    DirInfo di;
+    mtl_get_sample_info(*sc, sc->materials[material], si, V3(dirIn[0], dirIn[1], dirIn[2]), di);
+    out[0] = di.mult.x; out[1] = di.mult.y; out[2] = di.mult.z;
+    out[3] = di.prob; out[4] = di.dist; out[5] = (float)di.lobe;
+    return 0;
+}
+
+// per-sample radiance of (x,y,s) triples: out[i] = {r,g,b,primaryDist}
+int orc_trace_samples(void* s, const rtx_camera* cam, const rtx_render_params* rp, void* photons, const int* xys,
+                      size_t n, float* out) {
+    Scene* sc = (Scene*)s;
+    Camera c = camera_from(cam);
+    int stride = rp->index_stride > 0 ? rp->index_stride : 1024;
+    for (size_t i = 0; i < n; ++i) {
+        int x = xys[3 * i], y = xys[3 * i + 1], sIdx = xys[3 * i + 2];
+        float shx, shy;
+        pixel_shifts(x, y, shx, shy);
+        int sampleIndex = (y * c.W + x) * stride + (sIdx + 1);
+        float jx = std::fmod(halton(sampleIndex, 2) + shx, 1.0f) - 0.5f;
+        float jy = std::fmod(halton(sampleIndex, 3) + shy, 1.0f) - 0.5f;
+        Ray r = generate_ray(c, float(x) + 0.5f + jx, float(y) + 0.5f + jy, sampleIndex);
+        PathResult pr = trace_path(*sc, c, r, x, y, sIdx, (PhotonMapper*)photons, rp->max_bounces, rp->seed, nullptr);
+        out[4 * i] = pr.radiance.x; out[4 * i + 1] = pr.radiance.y; out[4 * i + 2] = pr.radiance.z;
+        out[4 * i + 3] = pr.primaryDist;
+    }
+    return 0;
+}
+
+// CastRays. Outputs (any may be NULL): accum[W*H*4], count, z, albedo[W*H*4], normal[W*H*4] raw film;
+// linear[W*H*3], rgb8[W*H*3] resolved. counters[3] = primary, bounce, shadow-hop rays. Returns wall seconds in *secs.
+int orc_render(void* s, const rtx_camera* cam, const rtx_render_params* rp, void* photons, int nthreads, int subset_stride,
+               float* accum, int* count, float* z, float* albedo, float* normal, float* linear, unsigned char* rgb8,
+               uint64_t* counters, double* secs) {
+    Scene* sc = (Scene*)s;
+    Camera c = camera_from(cam);
+    Film film;
+    film.init(c.W, c.H);
+    PathCounters pc;
+    auto t0 = std::chrono::steady_clock::now();
+    render(*sc, c, *rp, (PhotonMapper*)photons, film, nthreads, subset_stride, &pc);
+    auto t1 = std::chrono::steady_clock::now();
+    if (secs) *secs = std::chrono::duration<double>(t1 - t0).count();
+    size_t n = (size_t)c.W * c.H;
+    if (accum) std::memcpy(accum, film.accum.data(), n * 16);
+    if (count) std::memcpy(count, film.count.data(), n * 4);
+    if (z) std::memcpy(z, film.z.data(), n * 4);
+    if (albedo) std::memcpy(albedo, film.albedo.data(), n * 16);
+    if (normal) std::memcpy(normal, film.normal.data(), n * 16);
+    for (size_t i = 0; i < n; ++i) {
+        float w = film.accum[i * 4 + 3];
+        V3 fin(0, 0, 0);
+        if (w > 0.0f) fin = V3(film.accum[i * 4] / w, film.accum[i * 4 + 1] / w, film.accum[i * 4 + 2] / w);
+        if (linear) { linear[3 * i] = fin.x; linear[3 * i + 1] = fin.y; linear[3 * i + 2] = fin.z; }
+        if (rgb8) to_color24(fin, c.srgb, rgb8 + 3 * i);
+    }
+    if (counters) { counters[0] = pc.primary; counters[1] = pc.bounce; counters[2] = pc.shadow; }
+    return 0;
+}
+
+// mergeToImage + ToColor24 on a raw film (used to resolve reduced multi-rank films)
+int orc_film_resolve(const float* accum, int W, int H, int srgb, float* linear, unsigned char* rgb8) {
+    size_t n = (size_t)W * H;
+    for (size_t i = 0; i < n; ++i) {
+        float w = accum[i * 4 + 3];
+        V3 fin(0, 0, 0);
+        if (w > 0.0f) fin = V3(accum[i * 4] / w, accum[i * 4 + 1] / w, accum[i * 4 + 2] / w);
+        if (linear) { linear[3 * i] = fin.x; linear[3 * i + 1] = fin.y; linear[3 * i + 2] = fin.z; }
+        if (rgb8) to_color24(fin, srgb != 0, rgb8 + 3 * i);
+    }
+    return 0;
+}
+
+// photon mapping
+int orc_photon_build(void* s, const rtx_photon_params* pp, void** out) {
+    *out = photon_build(*(Scene*)s, pp);
+    return 0;
+}
+// PhotonMapBuilder.cpp:38-50 scaling + PrepareForIrradianceEstimation
+int orc_photon_finalize(void* p, int total_emitted) {
+    PhotonMapper* pm = (PhotonMapper*)p;
+    if (!pm->global.ph.empty()) {
+        pm->global.scale(1.0f / float(total_emitted));
+        pm->global.prepare(pm->photonRadius);
+    }
+    if (!pm->caustic.ph.empty()) {
+        pm->caustic.scale(1.0f / float(pm->caustic.ph.size()));
+        pm->caustic.prepare(pm->causticRadius);
+    }
+    return 0;
+}
+void orc_photon_destroy(void* p) { delete (PhotonMapper*)p; }
+int orc_photon_info(void* p, uint64_t counts[3], float radii[2]) {
+    PhotonMapper* pm = (PhotonMapper*)p;
+    counts[0] = pm->global.ph.size();
+    counts[1] = pm->caustic.ph.size();
+    counts[2] = pm->rays;
+    radii[0] = pm->photonRadius;
+    radii[1] = pm->causticRadius;
+    return 0;
+}
+int64_t orc_photon_download(void* p, int which, rtx_photon* out, size_t cap) {
+    PhotonMapper* pm = (PhotonMapper*)p;
+    auto& v = which ? pm->caustic.ph : pm->global.ph;
+    size_t n = std::min(cap, v.size());
+    std::memcpy(out, v.data(), n * sizeof(rtx_photon));
+    return (int64_t)n;
+}
+int orc_photon_append(void* p, int which, const rtx_photon* in, size_t n) {
+    PhotonMapper* pm = (PhotonMapper*)p;
+    auto& v = which ? pm->caustic.ph : pm->global.ph;
+    v.insert(v.end(), in, in + n);
+    return 0;
+}
+int orc_photon_estimate(void* p, int which, const float* pos, const float* nrm, size_t n, float* irr) {
+    PhotonMapper* pm = (PhotonMapper*)p;
+    const PhotonMap& m = which ? pm->caustic : pm->global;
+    float radius = which ? pm->causticRadius : pm->photonRadius;
+    int maxPhotons = pm->searchCount <= 30 ? 30 : (pm->searchCount <= 50 ? 50 : 100);
+    for (size_t i = 0; i < n; ++i) {
+        V3 r = m.estimate(maxPhotons, radius, V3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]),
+                          V3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]));
+        irr[3 * i] = r.x; irr[3 * i + 1] = r.y; irr[3 * i + 2] = r.z;
+    }
+    return 0;
+}
+
+}  // extern "C"
