@@ -294,8 +294,12 @@ void* rtx_photon_device_ptr(const rtx_photons* p, int which);
 int rtx_photon_estimate(rtx_photons* p, int which, const float* positions, const float* normals, size_t n,
                         float* irradiance);
 
-/* Enables per-ray node/triangle counters (instrumented traversal; slower). */
+/* Enables per-ray node/triangle counters (instrumented traversal; slower) and zeroes them. */
 int rtx_set_counters(rtx_scene* scene, int enabled);
+
+/* out[0]=BVH nodes visited, [1]=triangles tested, [2]=rays traced since rtx_set_counters(scene, 1). These give
+ * the algorithmic bytes per ray of SURVEY.md §8(d): 48 + nodes*64 + tris*48. */
+int rtx_get_counters(rtx_scene* scene, uint64_t out[3]);
 
 #ifdef __cplusplus
 }

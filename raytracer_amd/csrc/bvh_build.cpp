@@ -1,0 +1,505 @@
+// Host-side scene flattening and BVH construction (see bvh_build.h, layout.h).
+#include "bvh_build.h"
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace {
+
+struct AABB {
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+    void add(const float* p) {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], p[a]);
+            hi[a] = std::max(hi[a], p[a]);
+        }
+    }
+    void add(const AABB& b) {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], b.lo[a]);
+            hi[a] = std::max(hi[a], b.hi[a]);
+        }
+    }
+    float area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.0f;
+        return 2.0f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+struct N2 {
+    AABB box;
+    int left = -1, right = -1;  // inner
+    int first = 0, count = 0;   // leaf when count > 0 (range in idx)
+};
+
+struct Builder {
+    std::vector<AABB> pbox;
+    std::vector<float> cen;  // 3 per prim
+    std::vector<int> idx;
+    std::vector<N2> nodes;
+    std::atomic<int> nextNode{0};
+    int maxPar = 4;
+
+    int alloc() { return nextNode.fetch_add(1); }
+
+    void build(int id, int lo, int hi, int parDepth) {
+        AABB box, cb;
+        for (int i = lo; i < hi; ++i) {
+            box.add(pbox[idx[i]]);
+            cb.add(&cen[3 * (size_t)idx[i]]);
+        }
+        nodes[id].box = box;
+        const int n = hi - lo;
+        if (n <= RTX_MAX_LEAF) {
+            nodes[id].first = lo;
+            nodes[id].count = n;
+            return;
+        }
+        // binned SAH over the three axes
+        const int NB = 16;
+        int bestAxis = -1, bestSplit = -1;
+        float bestCost = 1e30f;
+        for (int a = 0; a < 3; ++a) {
+            float c0 = cb.lo[a], c1 = cb.hi[a];
+            if (!(c1 > c0)) continue;
+            float k = NB / (c1 - c0);
+            AABB bb[NB];
+            int bc[NB] = {0};
+            for (int i = lo; i < hi; ++i) {
+                int p = idx[i];
+                int b = std::min(NB - 1, std::max(0, (int)((cen[3 * (size_t)p + a] - c0) * k)));
+                bb[b].add(pbox[p]);
+                bc[b]++;
+            }
+            float rightArea[NB];
+            int rightCnt[NB];
+            AABB acc;
+            int cnt = 0;
+            for (int b = NB - 1; b > 0; --b) {
+                acc.add(bb[b]);
+                cnt += bc[b];
+                rightArea[b] = acc.area();
+                rightCnt[b] = cnt;
+            }
+            acc = AABB();
+            cnt = 0;
+            for (int b = 0; b < NB - 1; ++b) {
+                acc.add(bb[b]);
+                cnt += bc[b];
+                if (cnt == 0 || rightCnt[b + 1] == 0) continue;
+                // leaves hold up to 4 triangles: count cost in units of leaf fetches
+                float cost = acc.area() * (float)((cnt + 3) / 4) + rightArea[b + 1] * (float)((rightCnt[b + 1] + 3) / 4);
+                if (cost < bestCost) {
+                    bestCost = cost;
+                    bestAxis = a;
+                    bestSplit = b;
+                }
+            }
+        }
+        int mid;
+        if (bestAxis >= 0) {
+            float c0 = cb.lo[bestAxis], c1 = cb.hi[bestAxis];
+            float k = NB / (c1 - c0);
+            int a = bestAxis, s = bestSplit;
+            auto it = std::partition(idx.begin() + lo, idx.begin() + hi, [&](int p) {
+                int b = std::min(NB - 1, std::max(0, (int)((cen[3 * (size_t)p + a] - c0) * k)));
+                return b <= s;
+            });
+            mid = (int)(it - idx.begin());
+        } else {
+            mid = lo;
+        }
+        if (mid == lo || mid == hi) {
+            // degenerate (coincident centroids): split the index range in the middle, ordered by primitive id
+            mid = (lo + hi) / 2;
+            std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi);
+        }
+        int l = alloc(), r = alloc();
+        nodes[id].left = l;
+        nodes[id].right = r;
+        if (parDepth < maxPar && n > 32768) {
+            std::thread t([&, l, lo, mid, parDepth]() { build(l, lo, mid, parDepth + 1); });
+            build(r, mid, hi, parDepth + 1);
+            t.join();
+        } else {
+            build(l, lo, mid, maxPar);
+            build(r, mid, hi, maxPar);
+        }
+    }
+};
+
+struct SrcTri {
+    float v[3][3];
+    int obj, face;
+};
+
+inline void xf_point(const float* M, const float* p, float* o) {
+    o[0] = M[0] * p[0] + M[1] * p[1] + M[2] * p[2] + M[3];
+    o[1] = M[4] * p[0] + M[5] * p[1] + M[6] * p[2] + M[7];
+    o[2] = M[8] * p[0] + M[9] * p[1] + M[10] * p[2] + M[11];
+}
+inline bool is_identity(const float* M) {
+    static const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    return std::memcmp(M, I, sizeof(I)) == 0;
+}
+
+inline void invert34(const float* M, float* R) {
+    double a = M[0], b = M[1], c = M[2], d = M[4], e = M[5], f = M[6], g = M[8], h = M[9], i = M[10];
+    double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    double id = 1.0 / det;
+    double r[9] = {(e * i - f * h) * id, (c * h - b * i) * id, (b * f - c * e) * id,
+                   (f * g - d * i) * id, (a * i - c * g) * id, (c * d - a * f) * id,
+                   (d * h - e * g) * id, (b * g - a * h) * id, (a * e - b * d) * id};
+    for (int k = 0; k < 3; ++k) {
+        R[k * 4 + 0] = (float)r[k * 3 + 0];
+        R[k * 4 + 1] = (float)r[k * 3 + 1];
+        R[k * 4 + 2] = (float)r[k * 3 + 2];
+        R[k * 4 + 3] = (float)(-(r[k * 3 + 0] * M[3] + r[k * 3 + 1] * M[7] + r[k * 3 + 2] * M[11]));
+    }
+}
+
+inline float decode_q(float o, int q, float scale) { return std::fmaf((float)q, scale, o); }
+
+struct Emitter {
+    const Builder& B;
+    const std::vector<SrcTri>& src;
+    const rtx_scene_desc* desc;
+    const std::vector<int>& faceBase;
+    const std::vector<float>& itm;  // 12 per mesh: inverse of xform (normals use its transpose)
+    HostScene& out;
+    int maxDepth = 0;
+    std::string err;
+
+    void emit_tri(int p) {
+        const SrcTri& t = src[p];
+        TriRec r;
+        r.v0x = t.v[0][0]; r.v0y = t.v[0][1]; r.v0z = t.v[0][2];
+        // e1 = v1 - v0, e2 = v2 - v0 in fp32: the operands the reference forms per test (objects.cpp:146-147)
+        r.e1x = t.v[1][0] - t.v[0][0]; r.e1y = t.v[1][1] - t.v[0][1]; r.e1z = t.v[1][2] - t.v[0][2];
+        r.e2x = t.v[2][0] - t.v[0][0]; r.e2y = t.v[2][1] - t.v[0][1]; r.e2z = t.v[2][2] - t.v[0][2];
+        r.pad0 = r.pad1 = 0.0f;
+        r.prim = (uint32_t)(faceBase[t.obj] + t.face);
+        out.tris.push_back(r);
+
+        const rtx_mesh_desc& m = desc->meshes[t.obj];
+        TriAttr a;
+        std::memset(&a, 0, sizeof(a));
+        if (m.vn && m.nvn > 0) {
+            const int* fn = (m.fn ? m.fn : m.f) + 3 * (size_t)t.face;
+            float* dst[3] = {a.n0, a.n1, a.n2};
+            for (int k = 0; k < 3; ++k) {
+                const float* n = m.vn + 3 * (size_t)fn[k];
+                // normals go to world space by the inverse-transpose (Node::FromNodeCoords); the transform is
+                // the identity for every cerealBar object
+                const float* M = &itm[12 * (size_t)t.obj];
+                if (is_identity(m.xform)) {
+                    dst[k][0] = n[0]; dst[k][1] = n[1]; dst[k][2] = n[2];
+                } else {
+                    dst[k][0] = M[0] * n[0] + M[4] * n[1] + M[8] * n[2];
+                    dst[k][1] = M[1] * n[0] + M[5] * n[1] + M[9] * n[2];
+                    dst[k][2] = M[2] * n[0] + M[6] * n[1] + M[10] * n[2];
+                }
+            }
+        }
+        if (m.vt && m.nvt > 0) {
+            const int* ft = (m.ft ? m.ft : m.f) + 3 * (size_t)t.face;
+            float* dst[3] = {a.uv0, a.uv1, a.uv2};
+            for (int k = 0; k < 3; ++k) {
+                const float* uv = m.vt + 3 * (size_t)ft[k];
+                dst[k][0] = uv[0]; dst[k][1] = uv[1];
+            }
+        }
+        int mtl = m.face_mtl ? m.face_mtl[t.face] : 0;
+        if (mtl < 0) mtl = 0;
+        a.obj_mtl = (uint32_t)t.obj | ((uint32_t)(mtl & 0xFFFF) << 16);
+        out.attrs.push_back(a);
+    }
+
+    uint32_t emit(int id, int depth) {
+        const N2& n = B.nodes[id];
+        maxDepth = std::max(maxDepth, depth);
+        if (n.count > 0) {
+            uint32_t first = (uint32_t)out.tris.size();
+            for (int i = 0; i < n.count; ++i) emit_tri(B.idx[n.first + i]);
+            return RTX_LEAF_FLAG | (first << 3) | (uint32_t)(n.count - 1);
+        }
+        // collapse: pull up grandchildren of the child with the largest surface area until 4 children
+        int c[4] = {n.left, n.right, -1, -1};
+        int nc = 2;
+        while (nc < 4) {
+            int best = -1;
+            float bestA = -1.0f;
+            for (int i = 0; i < nc; ++i) {
+                const N2& ch = B.nodes[c[i]];
+                if (ch.count > 0) continue;
+                float a = ch.box.area();
+                if (a > bestA) {
+                    bestA = a;
+                    best = i;
+                }
+            }
+            if (best < 0) break;
+            int l = B.nodes[c[best]].left, r = B.nodes[c[best]].right;
+            c[best] = l;
+            c[nc++] = r;
+        }
+        uint32_t my = (uint32_t)out.nodes.size();
+        out.nodes.push_back(Node4{});
+        uint32_t refs[4] = {RTX_EMPTY_CHILD, RTX_EMPTY_CHILD, RTX_EMPTY_CHILD, RTX_EMPTY_CHILD};
+        for (int i = 0; i < nc; ++i) refs[i] = emit(c[i], depth + 1);
+        Node4 nd;
+        std::memset(&nd, 0, sizeof(nd));
+        nd.nchild = (uint8_t)nc;
+        nd.ox = n.box.lo[0]; nd.oy = n.box.lo[1]; nd.oz = n.box.lo[2];
+        const float o[3] = {nd.ox, nd.oy, nd.oz};
+        uint8_t* ebytes[3] = {&nd.ex, &nd.ey, &nd.ez};
+        for (int a = 0; a < 3; ++a) {
+            float extent = n.box.hi[a] - n.box.lo[a];
+            int E = 1;
+            if (extent > 0.0f) {
+                int e;
+                std::frexp(extent / 255.0f, &e);  // extent/255 = m * 2^e, m in [0.5,1)
+                E = e + 127;
+            }
+            if (E < 1) E = 1;
+            for (;; ++E) {
+                if (E > 254) {
+                    err = "scene extent too large to quantise";
+                    return my;
+                }
+                uint32_t bits = (uint32_t)E << 23;
+                float scale;
+                std::memcpy(&scale, &bits, 4);
+                bool ok = true;
+                for (int i = 0; i < 4; ++i) {
+                    if (i >= nc) {
+                        nd.qlo[a][i] = 255;  // inverted box: never hit
+                        nd.qhi[a][i] = 0;
+                        continue;
+                    }
+                    const AABB& cb = B.nodes[c[i]].box;
+                    int ql = (int)std::floor(((double)cb.lo[a] - (double)o[a]) / (double)scale);
+                    ql = std::min(255, std::max(0, ql));
+                    while (ql > 0 && decode_q(o[a], ql, scale) > cb.lo[a]) --ql;
+                    int qh = (int)std::ceil(((double)cb.hi[a] - (double)o[a]) / (double)scale);
+                    qh = std::max(0, qh);
+                    while (qh <= 255 && decode_q(o[a], qh, scale) < cb.hi[a]) ++qh;
+                    if (qh > 255) {
+                        ok = false;
+                        break;
+                    }
+                    nd.qlo[a][i] = (uint8_t)ql;
+                    nd.qhi[a][i] = (uint8_t)qh;
+                }
+                if (ok) break;
+            }
+            *ebytes[a] = (uint8_t)E;
+        }
+        for (int i = 0; i < 4; ++i) nd.child[i] = refs[i];
+        out.nodes[my] = nd;
+        return my;
+    }
+};
+
+}  // namespace
+
+bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& err) {
+    out = HostScene();
+    if (!desc || desc->n_meshes < 0) {
+        err = "null scene description";
+        return false;
+    }
+    if (desc->n_meshes > 65535) {
+        err = "more than 65535 objects";
+        return false;
+    }
+    std::vector<int> faceBase(desc->n_meshes, 0);
+    size_t total = 0;
+    for (int m = 0; m < desc->n_meshes; ++m) {
+        const rtx_mesh_desc& md = desc->meshes[m];
+        if (md.nf < 0 || md.nv < 0 || (md.nf > 0 && (!md.v || !md.f))) {
+            err = "mesh " + std::to_string(m) + ": missing vertex/face arrays";
+            return false;
+        }
+        if (md.material >= desc->n_materials) {
+            err = "mesh " + std::to_string(m) + ": material index out of range";
+            return false;
+        }
+        faceBase[m] = (int)total;
+        total += (size_t)md.nf;
+    }
+    if (total > (size_t)(1u << 27)) {
+        err = "more than 2^27 triangles";
+        return false;
+    }
+    std::vector<SrcTri> src(total);
+    std::vector<float> itm(12 * (size_t)std::max(1, desc->n_meshes));
+    for (int m = 0; m < desc->n_meshes; ++m) {
+        if (is_identity(desc->meshes[m].xform)) std::memcpy(&itm[12 * (size_t)m], desc->meshes[m].xform, 48);
+        else invert34(desc->meshes[m].xform, &itm[12 * (size_t)m]);
+    }
+    out.objs.resize(desc->n_meshes);
+    AABB rootBox;
+    for (int m = 0; m < desc->n_meshes; ++m) {
+        const rtx_mesh_desc& md = desc->meshes[m];
+        const bool ident = is_identity(md.xform);
+        ObjRec& o = out.objs[m];
+        o.material = md.material;
+        o.flags = ((md.vn && md.nvn > 0) ? OBJ_HAS_NORMALS : 0u) | ((md.vt && md.nvt > 0) ? OBJ_HAS_TEXCOORDS : 0u);
+        o.face_base = faceBase[m];
+        o.nf = md.nf;
+        for (int k = 0; k < 3 * md.nv; ++k)
+            if (!std::isfinite(md.v[k])) {
+                err = "mesh " + std::to_string(m) + ": non-finite vertex";
+                return false;
+            }
+        // object box in local coordinates, then its 8 corners in root coordinates (Node::GetChildBoundBox)
+        AABB local;
+        for (int k = 0; k < md.nv; ++k) local.add(md.v + 3 * (size_t)k);
+        if (md.nv > 0) {
+            if (ident) rootBox.add(local);
+            else
+                for (int c = 0; c < 8; ++c) {
+                    float p[3] = {(c & 1) ? local.hi[0] : local.lo[0], (c & 2) ? local.hi[1] : local.lo[1],
+                                  (c & 4) ? local.hi[2] : local.lo[2]};
+                    float w[3];
+                    xf_point(md.xform, p, w);
+                    rootBox.add(w);
+                }
+        }
+        for (int f = 0; f < md.nf; ++f) {
+            SrcTri& t = src[(size_t)faceBase[m] + f];
+            t.obj = m;
+            t.face = f;
+            for (int k = 0; k < 3; ++k) {
+                int vi = md.f[3 * (size_t)f + k];
+                if (vi < 0 || vi >= md.nv) {
+                    err = "mesh " + std::to_string(m) + ": vertex index out of range";
+                    return false;
+                }
+                if (ident) std::memcpy(t.v[k], md.v + 3 * (size_t)vi, 12);
+                else xf_point(md.xform, md.v + 3 * (size_t)vi, t.v[k]);
+            }
+            if (md.vn && md.nvn > 0) {
+                const int* fn = (md.fn ? md.fn : md.f) + 3 * (size_t)f;
+                for (int k = 0; k < 3; ++k)
+                    if (fn[k] < 0 || fn[k] >= md.nvn) {
+                        err = "mesh " + std::to_string(m) + ": normal index out of range";
+                        return false;
+                    }
+            }
+            if (md.vt && md.nvt > 0) {
+                const int* ft = (md.ft ? md.ft : md.f) + 3 * (size_t)f;
+                for (int k = 0; k < 3; ++k)
+                    if (ft[k] < 0 || ft[k] >= md.nvt) {
+                        err = "mesh " + std::to_string(m) + ": texcoord index out of range";
+                        return false;
+                    }
+            }
+        }
+    }
+    std::memcpy(out.bounds, rootBox.lo, 12);
+    std::memcpy(out.bounds + 3, rootBox.hi, 12);
+    if (total == 0) {
+        out.root = RTX_EMPTY_CHILD;
+        return true;
+    }
+    Builder B;
+    B.pbox.resize(total);
+    B.cen.resize(3 * total);
+    B.idx.resize(total);
+    for (size_t i = 0; i < total; ++i) {
+        AABB b;
+        for (int k = 0; k < 3; ++k) b.add(src[i].v[k]);
+        B.pbox[i] = b;
+        for (int a = 0; a < 3; ++a) B.cen[3 * i + a] = 0.5f * (b.lo[a] + b.hi[a]);
+        B.idx[i] = (int)i;
+    }
+    B.nodes.resize(2 * total + 1);
+    int root = B.alloc();
+    unsigned hc = std::thread::hardware_concurrency();
+    B.maxPar = hc >= 16 ? 5 : (hc >= 8 ? 4 : (hc >= 4 ? 3 : 2));
+    B.build(root, 0, (int)total, 0);
+
+    out.tris.reserve(total);
+    out.attrs.reserve(total);
+    out.nodes.reserve(total / 2 + 16);
+    Emitter E{B, src, desc, faceBase, itm, out};
+    out.root = E.emit(root, 0);
+    out.depth = E.maxDepth;
+    if (!E.err.empty()) {
+        err = E.err;
+        return false;
+    }
+    return true;
+}
+
+namespace {
+struct Validator {
+    const HostScene& hs;
+    std::vector<uint8_t> seen;
+    std::string err;
+    // returns the exact box of the subtree
+    AABB walk(uint32_t ref) {
+        AABB b;
+        if (ref & RTX_LEAF_FLAG) {
+            uint32_t first = (ref & 0x7FFFFFFFu) >> 3, cnt = (ref & 7u) + 1;
+            for (uint32_t i = first; i < first + cnt; ++i) {
+                if (i >= hs.tris.size()) {
+                    err = "leaf range out of bounds";
+                    return b;
+                }
+                if (seen[i]++) err = "triangle referenced twice";
+                const TriRec& t = hs.tris[i];
+                float v0[3] = {t.v0x, t.v0y, t.v0z};
+                float v1[3] = {t.v0x + t.e1x, t.v0y + t.e1y, t.v0z + t.e1z};
+                float v2[3] = {t.v0x + t.e2x, t.v0y + t.e2y, t.v0z + t.e2z};
+                b.add(v0);
+                b.add(v1);
+                b.add(v2);
+            }
+            return b;
+        }
+        if (ref >= hs.nodes.size()) {
+            err = "node index out of bounds";
+            return b;
+        }
+        const Node4& n = hs.nodes[ref];
+        const float o[3] = {n.ox, n.oy, n.oz};
+        const uint8_t e[3] = {n.ex, n.ey, n.ez};
+        for (int i = 0; i < 4; ++i) {
+            if (n.child[i] == RTX_EMPTY_CHILD) continue;
+            AABB cb = walk(n.child[i]);
+            if (!err.empty()) return b;
+            for (int a = 0; a < 3; ++a) {
+                uint32_t bits = (uint32_t)e[a] << 23;
+                float scale;
+                std::memcpy(&scale, &bits, 4);
+                float lo = decode_q(o[a], n.qlo[a][i], scale), hi = decode_q(o[a], n.qhi[a][i], scale);
+                // v1/v2 are re-derived as v0+e (one rounding each), allow that slack
+                float slack = 4e-7f * std::max(std::fabs(cb.lo[a]), std::fabs(cb.hi[a])) + 1e-30f;
+                if (lo > cb.lo[a] + slack || hi < cb.hi[a] - slack) {
+                    err = "quantised child box does not contain its subtree";
+                    return b;
+                }
+            }
+            b.add(cb);
+        }
+        return b;
+    }
+};
+}  // namespace
+
+std::string validate_host_scene(const HostScene& hs) {
+    if (hs.tris.size() != hs.attrs.size()) return "tris/attrs size mismatch";
+    if (hs.tris.empty()) return hs.root == RTX_EMPTY_CHILD ? "" : "empty scene with a root";
+    Validator v{hs, std::vector<uint8_t>(hs.tris.size(), 0), ""};
+    v.walk(hs.root);
+    if (!v.err.empty()) return v.err;
+    for (size_t i = 0; i < v.seen.size(); ++i)
+        if (v.seen[i] != 1) return "triangle not referenced exactly once";
+    return "";
+}

@@ -1,0 +1,25 @@
+// Host-side scene flattening: (Node,TriObj) pairs -> one quantised 4-wide BVH + compact triangle streams.
+// Replaces TriObj::BuildAcceleration (reference RayTracer/objects.cpp:128-138) and the scene-graph walk of
+// IntersectNodeLocal (RayTracer/IntersectNodeAdapter.h:23-97) by a single flat structure (layout.h).
+#pragma once
+#include <string>
+#include <vector>
+#include "layout.h"
+#include "../../include/rtx.h"
+
+struct HostScene {
+    std::vector<Node4> nodes;
+    std::vector<TriRec> tris;
+    std::vector<TriAttr> attrs;
+    std::vector<ObjRec> objs;
+    uint32_t root = RTX_EMPTY_CHILD;
+    float bounds[6] = {1e30f, 1e30f, 1e30f, -1e30f, -1e30f, -1e30f};
+    int depth = 0;
+};
+
+// Returns false and sets err on invalid input (index out of range, non-finite vertex, too many faces).
+bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& err);
+
+// Structural self-check used by the CPU tests: every triangle in exactly one leaf, every child box contains
+// its subtree, quantised boxes are conservative. Returns an empty string when consistent.
+std::string validate_host_scene(const HostScene& hs);

@@ -1,0 +1,166 @@
+// HIP kernels for ray casting on gfx950: extend (closest hit), pixel-centre ray generation, hit expansion and
+// the shadow-chain visibility query. See traverse.h / shadow.h for the device functions and their reference
+// citations.
+#include "kernels.h"
+#include "shadow.h"
+
+// Each wave pulls 64 consecutive rays at a time from a global cursor, so neighbouring (coherent) rays share a
+// wave and waves stay busy until the queue is drained; every wave leaves the loop once the cursor passes n.
+template <bool COUNT>
+__global__ __launch_bounds__(TRAV_BLOCK) void extend_kernel(DevScene sc, const float4* __restrict__ rays, uint32_t n,
+                                                            int hitSide, int withLights, float4* __restrict__ hits,
+                                                            uint32_t* workCounter, uint2* spill,
+                                                            unsigned long long* counters) {
+    __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    TravStack st{&lds_stack[threadIdx.x], spill + gtid, gridDim.x * blockDim.x};
+    uint32_t nodeCount = 0, triCount = 0, rayCount = 0;
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(workCounter, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n) break;
+        const uint32_t i = base + lane;
+        if (i < n) {
+            const float4 a = rays[2 * (size_t)i], b = rays[2 * (size_t)i + 1];
+            RayT r{a.x, a.y, a.z, b.x, b.y, b.z, a.w};
+            HitT h = traverse_closest<COUNT>(sc, r, hitSide, st, &nodeCount, &triCount);
+            if (withLights) intersect_lights(sc, r, h);
+            hits[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.slot));
+            if (COUNT) rayCount++;
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&counters[0], (unsigned long long)nodeCount);
+        atomicAdd(&counters[1], (unsigned long long)triCount);
+        atomicAdd(&counters[2], (unsigned long long)rayCount);
+    }
+}
+
+void launch_extend(const DevScene& sc, const LaunchCfg& cfg, const float4* rays, uint32_t n, int hitSide, int withLights,
+                   float4* hits) {
+    if (n == 0) return;
+    (void)hipMemsetAsync(cfg.workCounter, 0, sizeof(uint32_t), cfg.stream);
+    const uint32_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
+    const uint32_t grid = need < (uint32_t)cfg.gridBlocks ? need : (uint32_t)cfg.gridBlocks;
+    if (cfg.counting)
+        hipLaunchKernelGGL(extend_kernel<true>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, rays, n, hitSide,
+                           withLights, hits, cfg.workCounter, cfg.spill, cfg.counters);
+    else
+        hipLaunchKernelGGL(extend_kernel<false>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, rays, n, hitSide,
+                           withLights, hits, cfg.workCounter, cfg.spill, cfg.counters);
+}
+
+// CameraAdapter.h:7-27
+__global__ void primary_raygen_kernel(DevCamera cam, float4* __restrict__ rays) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= cam.W || y >= cam.H) return;
+    const float ndcX = (((float)x + 0.5f) / (float)cam.W) * 2.0f - 1.0f;
+    const float ndcY = 1.0f - (((float)y + 0.5f) / (float)cam.H) * 2.0f;
+    const float sx = ndcX * cam.halfX;
+    const float sy = ndcY * cam.halfY;
+    f3 dir = ld3(cam.r) * sx + ld3(cam.u) * sy + ld3(cam.f);
+    dir = normalized3(dir);
+    const size_t i = (size_t)y * cam.W + x;
+    rays[2 * i] = make_float4(cam.pos[0], cam.pos[1], cam.pos[2], RTX_BIG);
+    rays[2 * i + 1] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+}
+
+void launch_primary_raygen(const DevCamera& cam, float4* rays, hipStream_t stream) {
+    dim3 block(64, 4), grid((cam.W + 63) / 64, (cam.H + 3) / 4);
+    hipLaunchKernelGGL(primary_raygen_kernel, grid, block, 0, stream, cam, rays);
+}
+
+__global__ void expand_hits_kernel(DevScene sc, const float4* __restrict__ rays, const float4* __restrict__ hits,
+                                   uint32_t n, rtx_hit* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = rays[2 * (size_t)i], b = rays[2 * (size_t)i + 1];
+    const float4 hv = hits[i];
+    RayT r{a.x, a.y, a.z, b.x, b.y, b.z, a.w};
+    HitT h{hv.x, hv.y, hv.z, __float_as_int(hv.w)};
+    rtx_hit o;
+    o.t = h.t;
+    o.obj = -1;
+    o.face = -1;
+    o.mtl_id = 0;
+    o.front = 1;
+    o.light = -1;
+    o.bu = 0.0f;
+    o.bv = 0.0f;
+    for (int k = 0; k < 3; ++k) {
+        o.p[k] = o.N[k] = o.GN[k] = o.uvw[k] = o.dpdu[k] = o.dpdv[k] = 0.0f;
+    }
+    if (h.slot != -1) {
+        SurfHit s;
+        if (h.slot >= 0) resolve_triangle(sc, r, h, s);
+        else resolve_light(sc, r, h, s);
+        o.obj = s.obj;
+        o.face = s.face;
+        o.mtl_id = s.mtlID;
+        o.front = s.front ? 1 : 0;
+        o.light = s.light;
+        o.bu = h.u;
+        o.bv = h.v;
+        o.p[0] = s.p.x; o.p[1] = s.p.y; o.p[2] = s.p.z;
+        o.N[0] = s.N.x; o.N[1] = s.N.y; o.N[2] = s.N.z;
+        o.GN[0] = s.GN.x; o.GN[1] = s.GN.y; o.GN[2] = s.GN.z;
+        o.uvw[0] = s.uvw.x; o.uvw[1] = s.uvw.y; o.uvw[2] = s.uvw.z;
+        o.dpdu[0] = s.dpdu.x; o.dpdu[1] = s.dpdu.y; o.dpdu[2] = s.dpdu.z;
+        o.dpdv[0] = s.dpdv.x; o.dpdv[1] = s.dpdv.y; o.dpdv[2] = s.dpdv.z;
+    }
+    out[i] = o;
+}
+
+void launch_expand_hits(const DevScene& sc, const float4* rays, const float4* hits, uint32_t n, rtx_hit* out,
+                        hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(expand_hits_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sc, rays, hits, n, out);
+}
+
+__global__ __launch_bounds__(TRAV_BLOCK) void visibility_kernel(DevScene sc, const float4* __restrict__ rays,
+                                                                const float4* __restrict__ normals, uint32_t n,
+                                                                int useTransmittance, float* __restrict__ vis,
+                                                                uint32_t* workCounter, uint2* spill,
+                                                                unsigned long long* hopCounter) {
+    __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    TravStack st{&lds_stack[threadIdx.x], spill + gtid, gridDim.x * blockDim.x};
+    uint32_t hops = 0, nc = 0, tc = 0;
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(workCounter, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n) break;
+        const uint32_t i = base + lane;
+        if (i < n) {
+            const float4 a = rays[2 * (size_t)i], b = rays[2 * (size_t)i + 1];
+            const float4 nn = normals[i];
+            vis[i] = visible_chain<false>(sc, mk3(a.x, a.y, a.z), mk3(nn.x, nn.y, nn.z), mk3(b.x, b.y, b.z), a.w,
+                                          useTransmittance != 0, st, &hops, &nc, &tc);
+        }
+    }
+    if (hopCounter) atomicAdd(hopCounter, (unsigned long long)hops);
+}
+
+void launch_visibility(const DevScene& sc, const LaunchCfg& cfg, const float4* rays, const float4* normals, uint32_t n,
+                       int useTransmittance, float* vis, unsigned long long* hopCounter) {
+    if (n == 0) return;
+    (void)hipMemsetAsync(cfg.workCounter, 0, sizeof(uint32_t), cfg.stream);
+    const uint32_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
+    const uint32_t grid = need < (uint32_t)cfg.gridBlocks ? need : (uint32_t)cfg.gridBlocks;
+    hipLaunchKernelGGL(visibility_kernel, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, rays, normals, n,
+                       useTransmittance, vis, cfg.workCounter, cfg.spill, hopCounter);
+}
+
+int query_resident_blocks(int which) {
+    int nb = 0;
+    hipError_t e;
+    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, extend_kernel<false>, TRAV_BLOCK, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, visibility_kernel, TRAV_BLOCK, 0);
+    if (e != hipSuccess || nb < 1) nb = 2;
+    return nb;
+}

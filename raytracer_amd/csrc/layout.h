@@ -1,0 +1,101 @@
+// HBM data layout of the flattened scene (shared by the host builder and the HIP kernels).
+//
+// The reference keeps one pointer-based cy::BVHTriMesh per TriObj (objects.cpp:136, triobj_bvh.cpp:13-34) and
+// walks the scene graph per ray (IntersectNodeAdapter.h:23-97). Here all (Node,TriObj) pairs are baked into
+// world space and merged into ONE 4-wide BVH with quantised child boxes:
+//
+//   Node4   64 B   origin (3 x f32) + 3 power-of-two scales + 4 x (6 x u8 box) + 4 child references
+//   TriRec  48 B   v0, e1 = v1-v0, e2 = v2-v0 (the operands of objects.cpp:146-151) + global triangle id
+//   TriAttr 64 B   vertex normals, texture coordinates, object / material id (objects.cpp:181-236)
+//
+// TriRec and TriAttr are stored in BVH (depth-first leaf) order so that neighbouring hits touch neighbouring
+// memory; a leaf references up to 4 consecutive records (leaf size 4 as in bvh.SetMesh(this, 4)).
+#pragma once
+#include <stdint.h>
+
+#define RTX_LEAF_FLAG 0x80000000u
+#define RTX_EMPTY_CHILD 0xFFFFFFFFu
+#define RTX_MAX_LEAF 4
+
+// traversal stack budget per lane: STACK_LDS entries in LDS, STACK_GLOBAL more in a global spill slab
+#define STACK_LDS 12
+#define STACK_GLOBAL 116
+#define TRAV_BLOCK 256
+
+// child reference: inner node -> node index; leaf -> LEAF_FLAG | (firstTri << 3) | (count - 1)
+struct Node4 {
+    float ox, oy, oz;       // quantisation origin = node box min
+    uint8_t ex, ey, ez, nchild;  // biased fp32 exponents of the per-axis scale (scale = 2^(e-127))
+    uint32_t child[4];
+    uint8_t qlo[3][4];      // [axis][child], box lo = o + q * scale (rounded down)
+    uint8_t qhi[3][4];      // box hi (rounded up)
+    uint32_t pad[2];
+};
+static_assert(sizeof(Node4) == 64, "Node4 must be 64 bytes");
+
+struct TriRec {
+    float v0x, v0y, v0z;
+    uint32_t prim;          // global triangle id = faceBase[obj] + face (object order, then face order)
+    float e1x, e1y, e1z, pad0;
+    float e2x, e2y, e2z, pad1;
+};
+static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+
+struct TriAttr {
+    float n0[3], n1[3], n2[3];
+    float uv0[2], uv1[2], uv2[2];
+    uint32_t obj_mtl;       // obj | (mtlID << 16)
+};
+static_assert(sizeof(TriAttr) == 64, "TriAttr must be 64 bytes");
+
+#define OBJ_HAS_NORMALS 1u
+#define OBJ_HAS_TEXCOORDS 2u
+struct ObjRec {
+    int material;           // index into materials, -1 = none
+    uint32_t flags;
+    int face_base;          // first global triangle id of this object
+    int nf;
+};
+
+struct DevTexMap {
+    const void* texels;     // uchar4 (RGB8) or float4 (RGB32F)
+    int format, width, height, pad;
+    float xf[12];
+};
+
+struct DevMaterial {
+    int type;
+    float kd[3]; int kd_tex;
+    float ks[3]; int ks_tex;
+    float kr[3]; int kr_tex;
+    float kt[3]; int kt_tex;
+    float ke[3]; int ke_tex;
+    float gloss, ior;
+    float absorption[3];
+    int bump_tex;
+    float bump_scale;
+};
+
+struct DevLight {
+    float pos[3];
+    float size;
+    float intensity[3];
+    float attenuation;
+};
+
+// Everything a kernel needs, passed by value as a kernel argument (lives in SGPRs / kernarg segment).
+struct DevScene {
+    const Node4* nodes;
+    const TriRec* tris;
+    const TriAttr* attrs;
+    const ObjRec* objs;
+    const DevMaterial* mtls;
+    const DevTexMap* texmaps;
+    uint32_t root;          // child reference of the root (a leaf reference for tiny scenes)
+    int n_tris, n_nodes, n_objs, n_lights, n_mtls;
+    float bounds[6];        // rootNode.GetChildBoundBox()
+    DevLight lights[8];
+    float env[3]; int env_tex;
+    float bg[3];  int bg_tex;
+    float bg_emission;
+};

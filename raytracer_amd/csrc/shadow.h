@@ -1,0 +1,71 @@
+// Device-side shadow query: Visible() / VisibleSimple() of the reference (RayTracer/RayCaster.cpp:178-278).
+// One lane runs the whole chain: up to 8 closest-hit hops through transmissive surfaces, each attenuated by
+// (1 - Schlick Fresnel) * max(kt); an opaque surface ends the chain with 0.
+#pragma once
+#include "surface.h"
+
+// RayCaster.cpp:108-112
+__device__ __forceinline__ f3 offset_point(f3 p, f3 n, f3 dir) {
+    const f3 nn = safe_normalize3(n);
+    const float sign = dot3(dir, nn) >= 0.0f ? 1.0f : -1.0f;
+    return p + nn * (1e-4f * sign);
+}
+
+// Geometric normal + front flag of a triangle hit (objects.cpp:175-177,190) without the rest of HitInfo.
+__device__ __forceinline__ void triangle_gn(const DevScene& sc, const RayT& r, int slot, f3& GN, bool& front, int& obj) {
+    const float4* tris4 = reinterpret_cast<const float4*>(sc.tris);
+    const float4 b = tris4[(size_t)slot * 3 + 1];
+    const float4 c = tris4[(size_t)slot * 3 + 2];
+    GN = cross3(mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z));
+    const float l2 = len2_3(GN);
+    if (l2 > 0.0f) GN = GN / sqrtf(l2);
+    else GN = mk3(0.0f, 0.0f, 1.0f);
+    front = dot3(mk3(r.dx, r.dy, r.dz), GN) < 0.0f;
+    obj = (int)(sc.attrs[slot].obj_mtl & 0xFFFFu);
+}
+
+template <bool COUNT>
+__device__ __forceinline__ float visible_chain(const DevScene& sc, f3 origin, f3 normal, f3 dirIn, float maxDist,
+                                               bool useTransmittance, TravStack st, uint32_t* hops, uint32_t* nodeCount,
+                                               uint32_t* triCount) {
+    const f3 d = safe_normalize3(dirIn);
+    f3 o = offset_point(origin, normal, dirIn);
+    const int kMaxHops = useTransmittance ? 8 : 1;
+    float visibility = 1.0f;
+    for (int hop = 0; hop < kMaxHops; ++hop) {
+        RayT r{o.x, o.y, o.z, d.x, d.y, d.z, maxDist};
+        (*hops)++;
+        HitT h = traverse_closest<COUNT>(sc, r, RTX_HIT_FRONT_AND_BACK, st, nodeCount, triCount);
+        intersect_lights(sc, r, h);
+        if (h.slot == -1) return visibility;   // nothing blocking
+        if (h.slot <= -2) return visibility;   // hit the light itself
+        const f3 hp = o + d * h.t;
+        const float dist = len3(hp - o);
+        if (dist >= maxDist - 1e-4f) return visibility;
+        if (!useTransmittance) return 0.0f;    // VisibleSimple :189
+        f3 GN;
+        bool front;
+        int obj;
+        triangle_gn(sc, r, h.slot, GN, front, obj);
+        const int mi = sc.objs[obj].material;
+        if (mi < 0) return 0.0f;
+        const DevMaterial& m = sc.mtls[mi];
+        const float transFactor = fmaxf(m.kt[0], fmaxf(m.kt[1], m.kt[2]));
+        if (transFactor <= 0.0f) return 0.0f;
+        const float ior = m.ior;
+        float cosTheta = fabsf(dot3(GN, -d));
+        const float etaI = front ? 1.0f : ior;
+        const float etaT = front ? ior : 1.0f;
+        cosTheta = fminf(fmaxf(cosTheta, 0.0f), 1.0f);
+        float r0 = (etaI - etaT) / (etaI + etaT);
+        r0 = r0 * r0;
+        const float F = r0 + (1.0f - r0) * powf(1.0f - cosTheta, 5.0f);
+        const float transmit = fmaxf(0.0f, fminf(1.0f, (1.0f - F) * transFactor));
+        visibility *= fmaxf(0.0f, fminf(1.0f, transmit));
+        if (visibility <= 1e-4f) return 0.0f;
+        o = offset_point(hp, GN, d);
+        maxDist -= dist;
+        if (maxDist <= 1e-4f) return visibility;
+    }
+    return useTransmittance ? 0.0f : visibility;
+}

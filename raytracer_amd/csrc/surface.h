@@ -1,0 +1,201 @@
+// Device-side reconstruction of the HitInfo fields from a compact hit {t,u,v,slot}, texture lookups and bump
+// mapping. Follows the tail of TriObj::IntersectTriangle (reference RayTracer/objects.cpp:172-240),
+// PointLight::IntersectRay (RayTracer/Shading.cpp:78-84) and ApplyBumpMapping (RayTracer/BumpMapping.h:9-70).
+#pragma once
+#include "traverse.h"
+#include "vec.h"
+
+struct SurfHit {
+    f3 p, N, GN, uvw, dpdu, dpdv;
+    float t;
+    int obj, mtlID, face, light;  // light = index or -1
+    bool front;
+};
+
+// TextureFile::Eval of the absent framework: tile, then bilinear with wrap-around (stand-in choice).
+__device__ __forceinline__ f3 tex_texel(const DevTexMap& tm, int x, int y) {
+    const size_t i = (size_t)y * tm.width + x;
+    if (tm.format == RTX_TEX_RGB8) {
+        const uchar4 c = reinterpret_cast<const uchar4*>(tm.texels)[i];
+        return mk3((float)c.x / 255.0f, (float)c.y / 255.0f, (float)c.z / 255.0f);
+    }
+    const float4 c = reinterpret_cast<const float4*>(tm.texels)[i];
+    return mk3(c.x, c.y, c.z);
+}
+__device__ __forceinline__ f3 tex_eval_raw(const DevTexMap& tm, f3 uvw) {
+    const int w = tm.width, h = tm.height;
+    if (w + h == 0) return mk3(0.0f);
+    float ux = uvw.x - (float)(int)uvw.x;
+    float uy = uvw.y - (float)(int)uvw.y;
+    if (ux < 0.0f) ux += 1.0f;
+    if (uy < 0.0f) uy += 1.0f;
+    const float x = (float)w * ux;
+    const float y = (float)h * uy;
+    int ix = (int)x;
+    int iy = (int)y;
+    const float fx = x - (float)ix;
+    const float fy = y - (float)iy;
+    if (ix >= w) ix -= (ix / w) * w;
+    int ixp = ix + 1;
+    if (ixp >= w) ixp -= w;
+    if (iy >= h) iy -= (iy / h) * h;
+    int iyp = iy + 1;
+    if (iyp >= h) iyp -= h;
+    return tex_texel(tm, ix, iy) * ((1 - fx) * (1 - fy)) + tex_texel(tm, ixp, iy) * (fx * (1 - fy)) +
+           tex_texel(tm, ix, iyp) * ((1 - fx) * fy) + tex_texel(tm, ixp, iyp) * (fx * fy);
+}
+__device__ __forceinline__ f3 xf_point3(const float* M, f3 p) {
+    return mk3(M[0] * p.x + M[1] * p.y + M[2] * p.z + M[3], M[4] * p.x + M[5] * p.y + M[6] * p.z + M[7],
+               M[8] * p.x + M[9] * p.y + M[10] * p.z + M[11]);
+}
+__device__ __forceinline__ f3 xf_vec3(const float* M, f3 p) {
+    return mk3(M[0] * p.x + M[1] * p.y + M[2] * p.z, M[4] * p.x + M[5] * p.y + M[6] * p.z,
+               M[8] * p.x + M[9] * p.y + M[10] * p.z);
+}
+__device__ __forceinline__ f3 tex_eval(const DevScene& sc, int tex, f3 uvw) {
+    const DevTexMap& tm = sc.texmaps[tex];
+    return tex_eval_raw(tm, xf_point3(tm.xf, uvw));
+}
+// TexturedColor::EvalEnvironment stand-in: rotate by the map transform, lat-long with +z as the pole.
+__device__ __forceinline__ f3 tex_eval_env(const DevScene& sc, int tex, f3 dir) {
+    const DevTexMap& tm = sc.texmaps[tex];
+    const f3 d = safe_normalize3(xf_vec3(tm.xf, dir));
+    const float u = atan2f(d.y, d.x) * (0.5f / 3.14159265358979323846f) + 0.5f;
+    const float v = acosf(fminf(1.0f, fmaxf(-1.0f, d.z))) * (1.0f / 3.14159265358979323846f);
+    return tex_eval_raw(tm, mk3(u, v, 0.0f));
+}
+// TexturedColor::Eval: value * texture (or value alone)
+__device__ __forceinline__ f3 eval_tc(const DevScene& sc, const float* value, int tex, f3 uvw) {
+    const f3 c = ld3(value);
+    if (tex >= 0) return c * tex_eval(sc, tex, uvw);
+    return c;
+}
+
+// HitInfo of a triangle hit: objects.cpp:172-240
+__device__ __forceinline__ void resolve_triangle(const DevScene& sc, const RayT& r, const HitT& h, SurfHit& s) {
+    const float4* tris4 = reinterpret_cast<const float4*>(sc.tris);
+    const float4 a = tris4[(size_t)h.slot * 3 + 0];
+    const float4 b = tris4[(size_t)h.slot * 3 + 1];
+    const float4 c = tris4[(size_t)h.slot * 3 + 2];
+    const float4* at4 = reinterpret_cast<const float4*>(sc.attrs + h.slot);
+    const float4 q0 = at4[0], q1 = at4[1], q2 = at4[2], q3 = at4[3];
+    const uint32_t obj_mtl = __float_as_uint(q3.w);
+    const int obj = (int)(obj_mtl & 0xFFFFu);
+    const ObjRec o = sc.objs[obj];
+    const f3 e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
+    const float u = h.u, v = h.v;
+    const float w = 1.0f - u - v;
+
+    f3 GN = cross3(e1, e2);
+    const float gnLen2 = len2_3(GN);
+    if (gnLen2 > 0.0f) GN = GN / sqrtf(gnLen2);
+    else GN = mk3(0.0f, 0.0f, 1.0f);
+
+    f3 N = GN;
+    if (o.flags & OBJ_HAS_NORMALS) {
+        const f3 n0 = mk3(q0.x, q0.y, q0.z), n1 = mk3(q0.w, q1.x, q1.y), n2 = mk3(q1.z, q1.w, q2.x);
+        N = (n0 * w + n1 * u + n2 * v);
+        if (len2_3(N) > 0.0f) N = normalized3(N);
+        else N = GN;
+    }
+    const f3 dir = mk3(r.dx, r.dy, r.dz);
+    s.front = dot3(dir, GN) < 0.0f;
+    s.t = h.t;
+    s.p = mk3(r.ox, r.oy, r.oz) + dir * h.t;
+    s.GN = GN;
+    s.N = N;
+    s.obj = obj;
+    s.mtlID = (int)(obj_mtl >> 16);
+    s.face = (int)__float_as_uint(a.w) - o.face_base;
+    s.light = -1;
+    s.dpdu = mk3(0.0f);
+    s.dpdv = mk3(0.0f);
+    if (o.flags & OBJ_HAS_TEXCOORDS) {
+        const f3 uv0 = mk3(q2.y, q2.z, 0.0f), uv1 = mk3(q2.w, q3.x, 0.0f), uv2 = mk3(q3.y, q3.z, 0.0f);
+        const f3 tex = uv0 * w + uv1 * u + uv2 * v;
+        s.uvw = mk3(tex.x, tex.y, 0.0f);
+        const f3 duv1 = uv1 - uv0;
+        const f3 duv2 = uv2 - uv0;
+        const float detUV = duv1.x * duv2.y - duv1.y * duv2.x;
+        if (fabsf(detUV) > RTX_EPS) {
+            const float invDetUV = 1.0f / detUV;
+            s.dpdu = (e1 * duv2.y - e2 * duv1.y) * invDetUV;
+            s.dpdv = (e2 * duv1.x - e1 * duv2.x) * invDetUV;
+        }
+    } else {
+        s.uvw = mk3(0.0f);
+    }
+    if (len2_3(s.dpdu) < RTX_EPS || len2_3(s.dpdv) < RTX_EPS) {
+        f3 tangent = (fabsf(GN.x) > 0.5f) ? mk3(-GN.y, GN.x, 0.0f) : mk3(0.0f, -GN.z, GN.y);
+        tangent = normalized3(tangent);
+        f3 bitangent = cross3(GN, tangent);
+        bitangent = normalized3(bitangent);
+        s.dpdu = tangent;
+        s.dpdv = bitangent;
+    }
+}
+
+// HitInfo of a light hit: Shading.cpp:78-84 on top of HitInfo::Init (uvw = 0.5 stand-in)
+__device__ __forceinline__ void resolve_light(const DevScene& sc, const RayT& r, const HitT& h, SurfHit& s) {
+    const int li = -2 - h.slot;
+    const DevLight& L = sc.lights[li];
+    const f3 dir = mk3(r.dx, r.dy, r.dz);
+    s.t = h.t;
+    s.p = mk3(r.ox, r.oy, r.oz) + dir * h.t;
+    s.N = safe_normalize3(s.p - ld3(L.pos));
+    s.GN = s.N;
+    s.mtlID = 0;
+    s.obj = -1;
+    s.face = -1;
+    s.light = li;
+    s.front = dot3(dir, s.N) <= 0.0f;
+    s.uvw = mk3(0.5f);
+    s.dpdu = mk3(0.0f);
+    s.dpdv = mk3(0.0f);
+}
+
+__device__ __forceinline__ void basis_from_normal(f3 n, f3& t, f3& b) {
+    if (fabsf(n.x) > 0.5f) t = cross3(mk3(0.0f, 1.0f, 0.0f), n);
+    else t = cross3(mk3(1.0f, 0.0f, 0.0f), n);
+    t = normalized3(t);
+    b = cross3(n, t);
+    b = normalized3(b);
+}
+
+// BumpMapping.h:17-70
+__device__ __forceinline__ void apply_bump(const DevScene& sc, const DevMaterial& m, SurfHit& h) {
+    if (m.bump_tex < 0) return;
+    f3 N = h.N;
+    if (len2_3(N) <= 0.0f) return;
+    N = normalized3(N);
+    f3 T = h.dpdu;
+    f3 B = h.dpdv;
+    if (len2_3(T) < 1e-10f || len2_3(B) < 1e-10f) {
+        basis_from_normal(N, T, B);
+    } else {
+        T = T - N * dot3(T, N);
+        if (len2_3(T) < 1e-10f) basis_from_normal(N, T, B);
+        else {
+            T = normalized3(T);
+            B = B - N * dot3(B, N);
+            B = B - T * dot3(B, T);
+            if (len2_3(B) < 1e-10f) B = cross3(N, T);
+            B = normalized3(B);
+        }
+    }
+    const DevTexMap& tm = sc.texmaps[m.bump_tex];
+    float du = 0.001f, dv = 0.001f;
+    const int maxDim = max(tm.width, tm.height);
+    if (maxDim > 0) du = dv = 1.0f / (float)maxDim;
+    const float h0 = luma1(tex_eval(sc, m.bump_tex, h.uvw));
+    const float hx = luma1(tex_eval(sc, m.bump_tex, h.uvw + mk3(du, 0.0f, 0.0f)));
+    const float hy = luma1(tex_eval(sc, m.bump_tex, h.uvw + mk3(0.0f, dv, 0.0f)));
+    const float invDu = (fabsf(du) > 1e-6f) ? 1.0f / du : 0.0f;
+    const float invDv = (fabsf(dv) > 1e-6f) ? 1.0f / dv : 0.0f;
+    const float dHdU = (hx - h0) * invDu * m.bump_scale;
+    const float dHdV = (hy - h0) * invDv * m.bump_scale;
+    f3 nT = mk3(-dHdU, -dHdV, 1.0f);
+    if (len2_3(nT) > 0.0f) nT = normalized3(nT);
+    const f3 bumped = T * nT.x + B * nT.y + N * nT.z;
+    if (len2_3(bumped) > 0.0f) h.N = normalized3(bumped);
+}

@@ -1,0 +1,220 @@
+// Device-side closest-hit traversal of the flattened scene (gfx950, wave64).
+//
+// Semantics follow the reference's closest-hit: Box::IntersectRay slab culls (RayTracer/scene_box.cpp:8-46)
+// around TriObj::IntersectTriangle (RayTracer/objects.cpp:140-171, Moller-Trumbore with EPS = 1e-7, inclusive
+// barycentric edges, accept 0 < EPS < t < current z). The reference recurses over a pointer BVH2 and always
+// visits both children (RayTracer/triobj_bvh.cpp:27-31); here each lane walks the quantised 4-wide BVH of
+// layout.h iteratively, nearest child first, with a short per-lane stack in LDS (8-byte entries
+// {child, entry distance}) that spills to a global slab when deeper than STACK_LDS.
+//
+// Exact-t ties: the reference keeps whichever triangle its scene/BVH order visits first (strict '<'); here the
+// smaller global triangle id wins, which is the order of the reference's brute-force path (objects.cpp:257-264).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "layout.h"
+
+#define RTX_EPS 1e-7f
+#define RTX_BIG 1.0e30f
+
+struct RayT {
+    float ox, oy, oz, dx, dy, dz, tmax;
+};
+struct HitT {
+    float t, u, v;
+    int slot;   // index into tris/attrs (BVH order); -1 = miss; -2-k = light k
+};
+
+// Per-lane traversal stack. LDS part is laid out [entry][thread] so that a wave's ds_read_b64/ds_write_b64 are
+// conflict-free; the spill part is [entry][global thread] so that a wave's accesses coalesce.
+struct TravStack {
+    uint2* lds;          // &stack[0][threadIdx.x]
+    uint2* spill;        // &slab[0 * stride + gtid]
+    uint32_t stride;     // total threads of the grid
+    __device__ __forceinline__ void push(int& sp, uint32_t ref, float t) {
+        uint2 e = make_uint2(ref, __float_as_uint(t));
+        if (sp < STACK_LDS) lds[sp * TRAV_BLOCK] = e;
+        else if (sp < STACK_LDS + STACK_GLOBAL) spill[(size_t)(sp - STACK_LDS) * stride] = e;
+        // deeper than STACK_LDS+STACK_GLOBAL cannot happen: host rejects BVHs with 3*depth+1 above the budget
+        ++sp;
+    }
+    __device__ __forceinline__ uint2 pop(int& sp) {
+        --sp;
+        if (sp < STACK_LDS) return lds[sp * TRAV_BLOCK];
+        return spill[(size_t)(sp - STACK_LDS) * stride];
+    }
+};
+
+__device__ __forceinline__ float scale_from_exp(uint32_t e) { return __uint_as_float(e << 23); }
+
+// One triangle, objects.cpp:140-171 and :190-191. The arithmetic order is the reference's; contraction is off so
+// that u, v and t are bit-identical to an fp32 CPU evaluation.
+__device__ __forceinline__ void test_triangle(const float4 a, const float4 b, const float4 c, const RayT& r, int hitSide,
+                                              uint32_t slot, const TriRec* tris, HitT& best, uint32_t& bestPrim) {
+#pragma clang fp contract(off)
+    const float e1x = b.x, e1y = b.y, e1z = b.z;
+    const float e2x = c.x, e2y = c.y, e2z = c.z;
+    // pvec = dir ^ e2
+    const float px = r.dy * e2z - r.dz * e2y;
+    const float py = r.dz * e2x - r.dx * e2z;
+    const float pz = r.dx * e2y - r.dy * e2x;
+    const float det = e1x * px + e1y * py + e1z * pz;
+    if (hitSide == RTX_HIT_FRONT && det <= RTX_EPS) return;
+    if (hitSide == RTX_HIT_BACK && det >= -RTX_EPS) return;
+    if (fabsf(det) < RTX_EPS) return;
+    const float invDet = 1.0f / det;
+    const float tx = r.ox - a.x, ty = r.oy - a.y, tz = r.oz - a.z;
+    const float u = (tx * px + ty * py + tz * pz) * invDet;
+    if (u < 0.0f || u > 1.0f) return;
+    // qvec = tvec ^ e1
+    const float qx = ty * e1z - tz * e1y;
+    const float qy = tz * e1x - tx * e1z;
+    const float qz = tx * e1y - ty * e1x;
+    const float v = (r.dx * qx + r.dy * qy + r.dz * qz) * invDet;
+    if (v < 0.0f || u + v > 1.0f) return;
+    const float t = (e2x * qx + e2y * qy + e2z * qz) * invDet;
+    if (t <= RTX_EPS) return;
+    const uint32_t prim = __float_as_uint(a.w);
+    if (t > best.t || (t == best.t && (best.slot < 0 || prim >= bestPrim))) return;  // objects.cpp:170 (+ tie rule)
+    if (hitSide != RTX_HIT_FRONT_AND_BACK) {
+        // objects.cpp:175-177,190-191: side test on the normalised geometric normal
+        float gx = e1y * e2z - e1z * e2y;
+        float gy = e1z * e2x - e1x * e2z;
+        float gz = e1x * e2y - e1y * e2x;
+        const float l2 = gx * gx + gy * gy + gz * gz;
+        if (l2 > 0.0f) {
+            const float l = sqrtf(l2);
+            gx = gx / l; gy = gy / l; gz = gz / l;
+        } else {
+            gx = 0.0f; gy = 0.0f; gz = 1.0f;
+        }
+        const bool front = (r.dx * gx + r.dy * gy + r.dz * gz) < 0.0f;
+        if ((hitSide == RTX_HIT_FRONT && !front) || (hitSide == RTX_HIT_BACK && front)) return;
+    }
+    best.t = t;
+    best.u = u;
+    best.v = v;
+    best.slot = (int)slot;
+    bestPrim = prim;
+}
+
+// Closest hit along r within (EPS, r.tmax). best.t starts at r.tmax (HitInfo::z in-out, IntersectNodeAdapter.h:28).
+// counters (optional): [0] += nodes visited, [1] += triangles tested.
+template <bool COUNT>
+__device__ __forceinline__ HitT traverse_closest(const DevScene& sc, const RayT& r, int hitSide, TravStack st,
+                                                 uint32_t* nodeCount, uint32_t* triCount) {
+    HitT best;
+    best.t = r.tmax;
+    best.u = 0.0f;
+    best.v = 0.0f;
+    best.slot = -1;
+    uint32_t bestPrim = 0xFFFFFFFFu;
+    if (sc.root == RTX_EMPTY_CHILD) return best;
+
+    const float idx = 1.0f / r.dx, idy = 1.0f / r.dy, idz = 1.0f / r.dz;
+    int sp = 0;
+    uint32_t cur = sc.root;
+    const uint4* nodes4 = reinterpret_cast<const uint4*>(sc.nodes);
+    const float4* tris4 = reinterpret_cast<const float4*>(sc.tris);
+
+    for (;;) {
+        if (!(cur & RTX_LEAF_FLAG)) {
+            // ---- inner node: 64 B = 4 x dwordx4 ----
+            const uint4 w0 = nodes4[(size_t)cur * 4 + 0];  // ox oy oz | ex ey ez n
+            const uint4 w1 = nodes4[(size_t)cur * 4 + 1];  // child[4]
+            const uint4 w2 = nodes4[(size_t)cur * 4 + 2];  // qlo x[4] y[4] z[4] | qhi x[4]
+            const uint4 w3 = nodes4[(size_t)cur * 4 + 3];  // qhi y[4] z[4] | pad
+            if (COUNT) (*nodeCount)++;
+            const float ox = __uint_as_float(w0.x), oy = __uint_as_float(w0.y), oz = __uint_as_float(w0.z);
+            const float sx = scale_from_exp(w0.w & 0xFFu), sy = scale_from_exp((w0.w >> 8) & 0xFFu),
+                        sz = scale_from_exp((w0.w >> 16) & 0xFFu);
+            float ct[4];
+            uint32_t cr[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t sh = 8u * i;
+                const float lox = fmaf((float)((w2.x >> sh) & 0xFFu), sx, ox);
+                const float loy = fmaf((float)((w2.y >> sh) & 0xFFu), sy, oy);
+                const float loz = fmaf((float)((w2.z >> sh) & 0xFFu), sz, oz);
+                const float hix = fmaf((float)((w2.w >> sh) & 0xFFu), sx, ox);
+                const float hiy = fmaf((float)((w3.x >> sh) & 0xFFu), sy, oy);
+                const float hiz = fmaf((float)((w3.y >> sh) & 0xFFu), sz, oz);
+                const float t0x = (lox - r.ox) * idx, t1x = (hix - r.ox) * idx;
+                const float t0y = (loy - r.oy) * idy, t1y = (hiy - r.oy) * idy;
+                const float t0z = (loz - r.oz) * idz, t1z = (hiz - r.oz) * idz;
+                // fminf/fmaxf drop NaNs (0 * inf when the origin lies on a slab plane of a parallel axis)
+                const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+                const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best.t));
+                // conservative: widen the far side by 2 ulp so that rounding never culls a box the ray grazes
+                const bool hit = (cr[i] != RTX_EMPTY_CHILD) && (tn <= tf * 1.0000004f);
+                ct[i] = hit ? tn : __builtin_inff();
+            }
+            // sort the four (distance, child) pairs, nearest first (5 compare-exchanges)
+#define RTX_CSWAP(a, b)                                   \
+    {                                                     \
+        const bool s_ = ct[b] < ct[a];                    \
+        const float tt_ = s_ ? ct[b] : ct[a];             \
+        const float tb_ = s_ ? ct[a] : ct[b];             \
+        const uint32_t rt_ = s_ ? cr[b] : cr[a];          \
+        const uint32_t rb_ = s_ ? cr[a] : cr[b];          \
+        ct[a] = tt_; ct[b] = tb_; cr[a] = rt_; cr[b] = rb_; \
+    }
+            RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
+#undef RTX_CSWAP
+            if (ct[3] != __builtin_inff()) st.push(sp, cr[3], ct[3]);
+            if (ct[2] != __builtin_inff()) st.push(sp, cr[2], ct[2]);
+            if (ct[1] != __builtin_inff()) st.push(sp, cr[1], ct[1]);
+            if (ct[0] != __builtin_inff()) {
+                cur = cr[0];
+                continue;
+            }
+        } else {
+            // ---- leaf: up to 4 consecutive 48-byte records ----
+            const uint32_t first = (cur & 0x7FFFFFFFu) >> 3;
+            const uint32_t cnt = (cur & 7u) + 1u;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const uint32_t slot = first + k;
+                const float4 a = tris4[(size_t)slot * 3 + 0];
+                const float4 b = tris4[(size_t)slot * 3 + 1];
+                const float4 c = tris4[(size_t)slot * 3 + 2];
+                if (COUNT) (*triCount)++;
+                test_triangle(a, b, c, r, hitSide, slot, sc.tris, best, bestPrim);
+            }
+        }
+        // ---- pop the next subtree that can still contain a closer (or tying) hit ----
+        bool found = false;
+        while (sp > 0) {
+            const uint2 e = st.pop(sp);
+            if (__uint_as_float(e.y) <= best.t) {
+                cur = e.x;
+                found = true;
+                break;
+            }
+        }
+        if (!found) break;
+    }
+    return best;
+}
+
+// PointLight::IntersectRay (Shading.cpp:65-86) for the renderable lights, applied after the scene hit as in
+// IntersectSceneWithLights (IntersectNodeAdapter.h:129-145): accept when 0 < t_light < current best.
+__device__ __forceinline__ void intersect_lights(const DevScene& sc, const RayT& r, HitT& best) {
+#pragma clang fp contract(off)
+    for (int i = 0; i < sc.n_lights; ++i) {
+        const DevLight& L = sc.lights[i];
+        if (L.size <= 0.0f) continue;
+        const float ocx = r.ox - L.pos[0], ocy = r.oy - L.pos[1], ocz = r.oz - L.pos[2];
+        const float b = ocx * r.dx + ocy * r.dy + ocz * r.dz;
+        const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - L.size * L.size;
+        const float disc = b * b - c;
+        if (disc < 0.0f) continue;
+        float t = -b - sqrtf(fmaxf(0.0f, disc));
+        if (t < 0.0f) t = -b + sqrtf(fmaxf(0.0f, disc));
+        if (t < 0.0f) continue;
+        if (t > 0.0f && t < best.t) {
+            best.t = t;
+            best.u = 0.0f;
+            best.v = 0.0f;
+            best.slot = -2 - i;
+        }
+    }
+}
