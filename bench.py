@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s and s/frame of the path-traced cerealbar-synth frame (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step is one full 1920x1080 frame at 128 spp through the hot path (ray-gen, extend, shade, shadow, resolve,
+film), config C3 of BASELINE.json, on the synthetic stand-in for assets/cerealBar.xml (the real geometry is
+Git-LFS only; see raytracer_amd/synth.py). With N ranks the 16x16 buckets are dealt round-robin to the ranks, every
+rank traces its buckets into a full-frame film in its own HBM, and the films are reduced to rank 0 over RCCL
+(sum of colour/weight/count, min of z: RayCaster.cpp:1182-1212) inside the timed region. `value` counts every ray
+segment traced by all ranks (primary + bounce + shadow hops) divided by the max-over-ranks wall time.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import raytracer_amd as ra  # noqa: E402
+from raytracer_amd import synth, _ffi  # noqa: E402
+from raytracer_amd.scene import render_params  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tri-scale", type=float, default=1.0)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=128)
+    ap.add_argument("--max-bounces", type=int, default=64)
+    ap.add_argument("--samples-per-pass", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=8)
+    return ap.parse_args()
+
+
+def make_film(W, H, dev):
+    n = W * H
+    t = dict(accum=torch.empty((n, 4), dtype=torch.float32, device=dev), count=torch.empty(n, dtype=torch.int32, device=dev),
+             z=torch.empty(n, dtype=torch.float32, device=dev), albedo=torch.empty((n, 4), dtype=torch.float32, device=dev),
+             normal=torch.empty((n, 4), dtype=torch.float32, device=dev))
+    f = _ffi.Film(t["accum"].data_ptr(), t["count"].data_ptr(), t["z"].data_ptr(), t["albedo"].data_ptr(), t["normal"].data_ptr())
+    return t, f
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world == 1 and a.gpus > 1:
+        print("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    ra.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    sd = synth.build_scene(a.tri_scale)
+    cam = synth.cerealbar_camera(a.width, a.height)
+    scene = ra.Scene(sd)
+    info = scene.info()
+    W, H = a.width, a.height
+    tens, film = make_film(W, H, dev)
+    rp = render_params(spp_min=a.spp, max_bounces=a.max_bounces, rank=rank, world=world, samples_per_pass=a.samples_per_pass)
+
+    def step():
+        ra.film_clear(film, W, H)
+        st = scene.render_accumulate(cam, rp, film)
+        if world > 1:
+            dist.reduce(tens["accum"], 0, op=dist.ReduceOp.SUM)
+            dist.reduce(tens["count"], 0, op=dist.ReduceOp.SUM)
+            dist.reduce(tens["z"], 0, op=dist.ReduceOp.MIN)
+        return st
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # algorithmic bytes per extend ray from an instrumented (counting) pass at 2 spp, untimed
+    scene.set_counters(True)
+    rp_c = render_params(spp_min=2, max_bounces=a.max_bounces, rank=rank, world=world)
+    ra.film_clear(film, W, H)
+    stc = scene.render_accumulate(cam, rp_c, film)
+    scene.set_counters(False)
+    ext_rays_c = stc["rays_primary"] + stc["rays_bounce"]
+    nodes_per_ray = stc["nodes_visited"] / max(1, ext_rays_c)
+    tris_per_ray = stc["tris_tested"] / max(1, ext_rays_c)
+    bytes_per_ray = 32 + 16 + nodes_per_ray * info["node_bytes"] + tris_per_ray * info["tri_bytes"]
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    agg = dict(rays=0, ext_rays=0, extend_ms=0.0, shadow_ms=0.0, shade_ms=0.0, launches=0, shadow_rays=0)
+    for _ in range(a.steps):
+        st = step()
+        agg["rays"] += st["rays_primary"] + st["rays_bounce"] + st["rays_shadow"]
+        agg["ext_rays"] += st["rays_primary"] + st["rays_bounce"]
+        agg["shadow_rays"] += st["rays_shadow"]
+        agg["extend_ms"] += st["extend_ms"]
+        agg["shadow_ms"] += st["shadow_ms"]
+        agg["shade_ms"] += st["shade_ms"]
+        agg["launches"] += st["extend_launches"]
+    sync()
+    dt = time.perf_counter() - t0
+
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    rays = torch.tensor([float(agg["rays"])], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    dt_max, rays_all = float(tt.item()), float(rays.item())
+
+    if rank == 0:
+        res = ra.film_resolve(film, cam)
+        finite = bool(np.isfinite(res["linear"]).all())
+        achieved = agg["ext_rays"] * bytes_per_ray / (agg["extend_ms"] * 1e-3) / 1e9 if agg["extend_ms"] > 0 else 0.0
+        out = {
+            "metric": "Mrays/s, cerealBar 1080p 128spp path traced (all ray segments: primary + bounce + shadow hops)",
+            "value": rays_all / dt_max / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": dt_max / a.steps * 1e3,
+            "s_per_frame": dt_max / a.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"C3: cerealbar-synth {W}x{H} {a.spp} spp path tracing max_bounces={a.max_bounces}",
+                       "triangles": info["triangles"], "bvh_nodes": info["nodes"], "tri_scale": a.tri_scale,
+                       "parallelism": f"tile-sharded x{world}, scene replicated, film reduce over RCCL"},
+            "rays_per_frame": rays_all / a.steps,
+            "image_finite": finite,
+            "mean_linear": float(res["linear"].mean()),
+            "roofline": {"bound": "hbm", "kernel": "extend_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
+                         "avg_launch_ms": agg["extend_ms"] / max(1, agg["launches"]), "launches": agg["launches"],
+                         "extend_Mrays_s": agg["ext_rays"] / max(1e-9, agg["extend_ms"]) / 1e3},
+            "kernel_ms_per_frame_rank0": {"extend": agg["extend_ms"] / a.steps, "shadow": agg["shadow_ms"] / a.steps,
+                                          "shade": agg["shade_ms"] / a.steps},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, cam, a)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sd, cam, a):
+    """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample of the
+    same workload: every 8th 16x16 bucket in x and y at a reduced sample count."""
+    from tests.oracle_ffi import OracleScene
+    threads = min(16, os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    osc = OracleScene(sd)
+    build_s = time.perf_counter() - t0
+    rp = render_params(spp_min=a.cpu_spp, max_bounces=a.max_bounces)
+    r = osc.render(cam, rp, nthreads=threads, subset_stride=8)
+    rays = r["rays"]["primary"] + r["rays"]["bounce"] + r["rays"]["shadow"]
+    return {"value": rays / r["seconds"] / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"every 8th 16x16 bucket in x and y (1/64 of the frame) at {a.cpu_spp} spp, same scene/camera/sampler; "
+                      f"{rays} ray segments in {r['seconds']:.2f} s (+{build_s:.1f} s BVH build, untimed)",
+            "seconds": r["seconds"], "paths": r["rays"]["primary"]}
+
+
+if __name__ == "__main__":
+    main()

@@ -270,6 +270,11 @@ int rtx_film_resolve(const rtx_film* film, const rtx_camera* cam, float* linear_
 int rtx_render(rtx_scene* scene, const rtx_camera* cam, const rtx_render_params* params, rtx_photons* photons,
                float* linear_rgb, unsigned char* rgb8, float* z, int* samples, rtx_stats* stats);
 
+/* Debug / parity aid with no counterpart in the reference: per-sample results of a fixed-spp render
+ * (spp_max == spp_min). out[(y*W+x)*spp + s] = {r, g, b (after the radiance clamp), primaryDist}, HOST array. */
+int rtx_render_samples(rtx_scene* scene, const rtx_camera* cam, const rtx_render_params* params, rtx_photons* photons,
+                       float* out, rtx_stats* stats);
+
 /* Replaces: PhotonMapBuilder::BuildPhotonMap (PhotonMapBuilder.cpp:20-60): emission + tracing on the GPU.
  * The stored photons stay in HBM inside the handle. */
 int rtx_photon_build(rtx_scene* scene, const rtx_photon_params* params, rtx_photons** out, rtx_stats* stats);
@@ -283,10 +288,11 @@ int rtx_photon_info(const rtx_photons* p, uint64_t counts[2], float radii[2]);
 int64_t rtx_photon_download(const rtx_photons* p, int which, rtx_photon* out, size_t capacity);
 
 /* Multi-GPU: replace the caustic/global photon set with the concatenation gathered from all ranks (device
- * pointer to n records) and rebuild the hash grid + power scaling (PhotonMapBuilder.cpp:38-50). */
+ * pointer to n raw records) and rebuild the hash grid + power scaling (PhotonMapBuilder.cpp:38-50).
+ * Raw record = 12 floats: {pos.xyz, bits(photonId*4+bounce)}, {dir.xyz, 0}, {unscaled power.rgb, 0}. */
 int rtx_photon_set(rtx_photons* p, int which, const void* photons_dev, size_t n, int total_emitted);
 
-/* Device address of the stored records (for RCCL all-gather by the caller). */
+/* Device address of the stored raw records (48 B each, layout above) for an RCCL all-gather by the caller. */
 void* rtx_photon_device_ptr(const rtx_photons* p, int which);
 
 /* Replaces: EstimateCaustics / PhotonMap::EstimateIrradiance<N,LINEAR> (RayCaster.cpp:143-153) for host

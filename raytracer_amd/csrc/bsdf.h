@@ -1,0 +1,494 @@
+// Device-side BSDF and light sampling: MtlBlinn/MtlPhong::GenerateSample/GetSampleInfo and
+// PointLight::GenerateSample/GetSampleInfo/RandomPhoton of the reference (RayTracer/Shading.cpp:31-737),
+// written for per-lane evaluation inside the wavefront shade kernel. Random numbers come from the counter-based
+// generator of vec.h keyed by (pixel, sample | photon) x bounce x draw slot.
+#pragma once
+#include "surface.h"
+
+#define LOBE_NONE 0
+#define LOBE_DIFFUSE 1
+#define LOBE_SPECULAR 2
+#define LOBE_TRANSMISSION 4
+#define LOBE_ALL 7
+#define PI_F 3.14159265358979323846f
+
+struct DirInfo {   // DirSampler::Info
+    f3 mult;
+    float prob, dist;
+    int lobe;
+};
+__device__ __forceinline__ void set_void(DirInfo& s) {
+    s.mult = mk3(0.0f);
+    s.prob = 0.0f;
+    s.dist = 0.0f;
+    s.lobe = LOBE_NONE;
+}
+
+// SamplerInfo after SetHit (RayCaster.cpp:393-399) + RNG key
+struct SampCtx {
+    f3 P, V, N, GN, uvw;
+    bool front;
+    unsigned long long key;
+    uint32_t stream;
+    __device__ __forceinline__ float rnd(uint32_t dim) const { return rng_draw(key, stream, dim); }
+};
+
+__device__ __forceinline__ void build_onb(f3 n, f3& u, f3& v) {   // Shading.cpp:31-37
+    if (fabsf(n.x) > 0.5f) u = cross3(mk3(0.0f, 1.0f, 0.0f), n);
+    else u = cross3(mk3(1.0f, 0.0f, 0.0f), n);
+    u = normalized3(u);
+    v = cross3(n, u);
+    v = normalized3(v);
+}
+__device__ __forceinline__ f3 reflect3(f3 w, f3 n) { return w - 2.0f * dot3(w, n) * n; }   // :39-43
+__device__ __forceinline__ float transmission_scale(float eta) { return fminf(eta * eta, 10.0f); }   // :45-48
+__device__ __forceinline__ float fresnel_dielectric(float cosThetaI, float etaI, float etaT) {        // :50-61
+    cosThetaI = clamp01f(fabsf(cosThetaI));
+    const float eta = etaI / etaT;
+    const float sin2T = eta * eta * (1.0f - cosThetaI * cosThetaI);
+    if (sin2T >= 1.0f) return 1.0f;
+    const float cosThetaT = sqrtf(fmaxf(0.0f, 1.0f - sin2T));
+    const float rParl = ((etaT * cosThetaI) - (etaI * cosThetaT)) / ((etaT * cosThetaI) + (etaI * cosThetaT));
+    const float rPerp = ((etaI * cosThetaI) - (etaT * cosThetaT)) / ((etaI * cosThetaI) + (etaT * cosThetaT));
+    return clamp01f(0.5f * (rParl * rParl + rPerp * rPerp));
+}
+
+struct PhongCtx {
+    f3 N, V, R, kd, ks, kr, kt;
+    float alpha, ior;
+    // lobe terms shared by sampling and evaluation (Shading.cpp:282-300 == :535-546)
+    f3 fresnelRef, transColor, specColor;
+};
+
+// Shading.cpp:227-278 — built ONCE per hit (the reference rebuilds it for every GenerateSample/GetSampleInfo call)
+__device__ __forceinline__ PhongCtx build_phong_ctx(const DevScene& sc, const DevMaterial& m, const SampCtx& s) {
+    PhongCtx c;
+    c.N = normalized3(s.N);
+    if (!s.front) c.N = -c.N;
+    c.V = safe_normalize3(s.V);
+    c.R = safe_normalize3(reflect3(-c.V, c.N));
+    c.kd = eval_tc(sc, m.kd, m.kd_tex, s.uvw);
+    c.ks = eval_tc(sc, m.ks, m.ks_tex, s.uvw);
+    c.kr = eval_tc(sc, m.kr, m.kr_tex, s.uvw);
+    c.kt = eval_tc(sc, m.kt, m.kt_tex, s.uvw);
+    c.alpha = fmaxf(0.001f, m.gloss);
+    c.ior = m.ior;
+    c.kd = clamp_max3(c.kd, 1.0f);
+    c.ks = clamp_max3(c.ks, 1.0f);
+    c.kr = clamp_max3(c.kr, 1.0f);
+    c.kt = clamp_max3(c.kt, 1.0f);
+    const float krMax = max3c(c.kr);
+    const float ktMax = max3c(c.kt);
+    if (krMax <= 0.0f && ktMax <= 0.0f) c.ks = clamp_max3(c.ks, 0.08f);
+    const float reserve = fminf(1.0f, krMax + ktMax);
+    const float available = fmaxf(0.0f, 1.0f - reserve);
+    const f3 kdks = c.kd + c.ks;
+    const float kdksMax = max3c(kdks);
+    if (kdksMax > 0.0f && kdksMax > available) {
+        const float scale = available / kdksMax;
+        c.kd = c.kd * scale;
+        c.ks = c.ks * scale;
+    }
+    const float etaI = s.front ? 1.0f : c.ior;
+    const float etaT = s.front ? c.ior : 1.0f;
+    const float F = (c.ior > 0.0f && max3c(c.kt) > 0.0f) ? fresnel_dielectric(fabsf(dot3(c.N, c.V)), etaI, etaT) : 0.0f;
+    c.fresnelRef = c.kt * F;
+    c.transColor = c.kt * (1.0f - F);
+    c.specColor = c.ks;
+    if (max3c(c.kr) > 0.0f) c.specColor = mk3(0.0f);
+    c.specColor = clamp_max3(c.specColor, 1.0f);
+    return c;
+}
+
+// Shading.cpp:280-531
+__device__ __forceinline__ bool sample_phong_blinn(const PhongCtx& ctx, bool phong, const SampCtx& s, f3& dir, DirInfo& si) {
+    set_void(si);
+    const float pd = luma1(ctx.kd);
+    const float ps = luma1(ctx.specColor);
+    const float pr = luma1(ctx.kr + ctx.fresnelRef);
+    const float pt = luma1(ctx.transColor);
+    const float total = pd + ps + pr + pt;
+    if (total <= 0.0f) return false;
+    const float r = s.rnd(DIM_LOBE) * total;
+    const float a = ctx.alpha;
+    const float u1 = s.rnd(DIM_U1);
+    const float u2 = s.rnd(DIM_U2);
+
+    if (r < pd) {
+        f3 U, Vb;
+        build_onb(ctx.N, U, Vb);
+        const float rxy = sqrtf(u1);
+        const float phi = 2.0f * PI_F * u2;
+        const float x = rxy * cosf(phi);
+        const float y = rxy * sinf(phi);
+        const float z = sqrtf(fmaxf(0.0f, 1.0f - u1));
+        dir = safe_normalize3(U * x + Vb * y + ctx.N * z);
+        const float cosN = fmaxf(0.0f, dot3(ctx.N, dir));
+        const float pdf = cosN / PI_F;
+        si.mult = ctx.kd * (1.0f / PI_F) * cosN;
+        si.prob = (pd / total) * pdf;
+        si.dist = 0.0f;
+        si.lobe = LOBE_DIFFUSE;
+        return si.prob > 0.0f && max3c(si.mult) > 0.0f;
+    } else if (r < pd + ps || r < pd + ps + pr) {
+        const bool specLobe = (r < pd + ps);
+        f3 color = ctx.specColor;
+        float pl = ps;
+        if (!specLobe) {
+            color = clamp_max3(ctx.kr + ctx.fresnelRef, 1.0f);
+            pl = pr;
+        }
+        const float phi = 2.0f * PI_F * u1;
+        const float cosT = powf(u2, 1.0f / (a + 1.0f));
+        const float sinT = sqrtf(fmaxf(0.0f, 1.0f - cosT * cosT));
+        if (phong) {
+            f3 U, Vb;
+            build_onb(ctx.R, U, Vb);
+            dir = safe_normalize3(U * (cosf(phi) * sinT) + Vb * (sinf(phi) * sinT) + ctx.R * cosT);
+            const float cosR = fmaxf(0.0f, dot3(ctx.R, dir));
+            const float cosN = fmaxf(0.0f, dot3(ctx.N, dir));
+            const float pdfDir = ((a + 1.0f) / (2.0f * PI_F)) * powf(cosR, a);
+            if (specLobe) si.mult = color * ((a + 2.0f) / (2.0f * PI_F)) * powf(cosR, a) * cosN;
+            else {
+                const float brdf = ((a + 2.0f) / (2.0f * PI_F)) * powf(cosR, a);
+                si.mult = color * brdf;
+            }
+            si.prob = (pl / total) * pdfDir;
+        } else {
+            f3 U, Vb;
+            build_onb(ctx.N, U, Vb);
+            const f3 h = safe_normalize3(U * (cosf(phi) * sinT) + Vb * (sinf(phi) * sinT) + ctx.N * cosT);
+            float VoH;
+            if (specLobe) {
+                dir = safe_normalize3(reflect3(-ctx.V, h));
+                VoH = fmaxf(0.0f, dot3(ctx.V, h));
+            } else {
+                VoH = dot3(ctx.V, h);
+                dir = safe_normalize3(2.0f * VoH * h - ctx.V);
+            }
+            const float NoL = fmaxf(0.0f, dot3(ctx.N, dir));
+            const float NoH = fmaxf(0.0f, dot3(ctx.N, h));
+            if (NoL <= 0.0f || NoH <= 0.0f || VoH <= 1e-6f) return false;
+            const float pdfH = ((a + 1.0f) / (2.0f * PI_F)) * powf(NoH, a);
+            const float pdfDir = pdfH / (4.0f * fmaxf(1e-6f, VoH));
+            const float invVoH = 1.0f / fmaxf(1e-6f, VoH);
+            si.mult = color * ((a + 8.0f) / (8.0f * PI_F)) * powf(NoH, a) * invVoH;
+            si.prob = (pl / total) * pdfDir;
+        }
+        si.dist = 0.0f;
+        si.lobe = LOBE_SPECULAR;
+        return si.prob > 0.0f && max3c(si.mult) > 0.0f;
+    } else {
+        const float eta = s.front ? 1.0f / ctx.ior : ctx.ior;
+        const f3 I = -ctx.V;
+        const float phi = 2.0f * PI_F * u1;
+        const float cosTheta = powf(u2, 1.0f / (a + 1.0f));
+        const float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
+        if (phong) {
+            const float cosI = -dot3(ctx.N, I);
+            const float k = 1.0f - eta * eta * (1.0f - cosI * cosI);
+            if (k < 0.0f) {
+                dir = safe_normalize3(reflect3(-ctx.V, ctx.N));
+                si.mult = ctx.transColor;
+                si.prob = (pt / total);
+                si.dist = -1.0f;
+                si.lobe = LOBE_SPECULAR;
+                return si.prob > 0.0f && max3c(si.mult) > 0.0f;
+            }
+            const float cosTIdeal = sqrtf(k);
+            const f3 T = safe_normalize3(eta * I + (eta * cosI - cosTIdeal) * ctx.N);
+            f3 U, Vb;
+            build_onb(T, U, Vb);
+            dir = safe_normalize3(U * (cosf(phi) * sinTheta) + Vb * (sinf(phi) * sinTheta) + T * cosTheta);
+            const float cosT = fmaxf(0.0f, dot3(T, dir));
+            const float absCosN = fabsf(dot3(ctx.N, dir));
+            if (cosT <= 0.0f || absCosN <= 0.0f) return false;
+            const float pdfDir = ((a + 1.0f) / (2.0f * PI_F)) * powf(cosT, a);
+            const float etaScale = transmission_scale(eta);
+            const f3 fTrans = ctx.transColor * ((a + 2.0f) / (2.0f * PI_F)) * powf(cosT, a);
+            si.mult = fTrans * etaScale;
+            si.prob = (pt / total) * pdfDir;
+        } else {
+            f3 U, Vb;
+            build_onb(ctx.N, U, Vb);
+            f3 h = safe_normalize3(U * (cosf(phi) * sinTheta) + Vb * (sinf(phi) * sinTheta) + ctx.N * cosTheta);
+            if (dot3(ctx.V, h) < 0.0f) h = -h;
+            const float cosI = -dot3(h, I);
+            const float k = 1.0f - eta * eta * (1.0f - cosI * cosI);
+            if (k < 0.0f) {
+                dir = safe_normalize3(reflect3(-ctx.V, h));
+                si.mult = ctx.transColor;
+                si.prob = (pt / total);
+                si.dist = -1.0f;
+                si.lobe = LOBE_SPECULAR;
+                return si.prob > 0.0f && max3c(si.mult) > 0.0f;
+            }
+            const float cosT = sqrtf(k);
+            dir = safe_normalize3(eta * I + (eta * cosI - cosT) * h);
+            const float absCosN = fabsf(dot3(ctx.N, dir));
+            const float VoH = dot3(ctx.V, h);
+            const float DoH = dot3(dir, h);
+            if (absCosN <= 0.0f || VoH <= 1e-6f || VoH * DoH >= 0.0f) return false;
+            const float denom = eta * VoH + DoH;
+            if (fabsf(denom) <= 1e-6f) return false;
+            const float pdfH = ((a + 1.0f) / (2.0f * PI_F)) * powf(fmaxf(0.0f, dot3(ctx.N, h)), a);
+            const float dwh_dwi = fabsf((eta * eta * DoH) / (denom * denom));
+            const float pdfDir = pdfH * dwh_dwi;
+            if (pdfDir <= 0.0f) return false;
+            const float etaScale = transmission_scale(eta);
+            const float NoH = fmaxf(0.0f, dot3(ctx.N, h));
+            const f3 fTrans = ctx.transColor * ((a + 2.0f) / (2.0f * PI_F)) * powf(NoH, a);
+            const float factor = fabsf(DoH * VoH) / fmaxf(1e-6f, fabsf(dot3(ctx.N, ctx.V)) * denom * denom);
+            si.mult = fTrans * etaScale * factor;
+            si.prob = (pt / total) * pdfDir;
+        }
+        si.dist = 0.0f;
+        si.lobe = LOBE_TRANSMISSION;
+        return si.prob > 0.0f && max3c(si.mult) > 0.0f;
+    }
+}
+
+// Shading.cpp:533-713
+__device__ __forceinline__ void evaluate_phong_blinn(const PhongCtx& ctx, bool phong, const SampCtx& s, f3 dirIn, DirInfo& si) {
+    set_void(si);
+    const f3 dir = safe_normalize3(dirIn);
+    const float cosN = dot3(ctx.N, dir);
+    f3 mult = mk3(0.0f);
+    float pdf = 0.0f;
+    const float a = ctx.alpha;
+    const float pd = luma1(ctx.kd);
+    const float ps = luma1(ctx.specColor);
+    const float pt = luma1(ctx.transColor);
+    int lobe = LOBE_NONE;
+
+    if (cosN > 0.0f) {
+        const float pr = luma1(ctx.kr + ctx.fresnelRef);
+        const float total = pd + ps + pr + pt;
+        if (total <= 0.0f) return;
+        const float pdfDiff = pd > 0.0f ? (cosN / PI_F) * (pd / total) : 0.0f;
+        float pdfRefl = 0.0f;
+        f3 fRefl = mk3(0.0f);
+        float pdfSpec = 0.0f;
+        bool hasSpec = false;
+        f3 fSpec = mk3(0.0f);
+        const f3 fDiff = (pd > 0.0f) ? ctx.kd * (1.0f / PI_F) : mk3(0.0f);
+        if (phong) {
+            const float cosR = fmaxf(0.0f, dot3(ctx.R, dir));
+            if (pr > 0.0f && cosR > 0.0f) {
+                const f3 reflColor = clamp_max3(ctx.kr + ctx.fresnelRef, 1.0f);
+                pdfRefl = ((a + 1.0f) / (2.0f * PI_F)) * powf(cosR, a);
+                pdfRefl *= pr / total;
+                fRefl = reflColor * ((a + 2.0f) / (2.0f * PI_F)) * powf(cosR, a);
+            }
+            if (ps > 0.0f && cosR > 0.0f) {
+                pdfSpec = ((a + 1.0f) / (2.0f * PI_F)) * powf(cosR, a);
+                pdfSpec *= ps / total;
+                hasSpec = true;
+                fSpec = ctx.specColor * ((a + 2.0f) / (2.0f * PI_F)) * powf(cosR, a);
+            }
+            mult = fRefl + (fDiff + fSpec) * cosN;
+        } else {
+            const f3 H = safe_normalize3(ctx.V + dir);
+            const float NoH = fmaxf(0.0f, dot3(ctx.N, H));
+            const float VoH = fmaxf(0.0f, dot3(ctx.V, H));
+            if (NoH > 0.0f && VoH > 1e-6f) {
+                const float powNoH = powf(NoH, a);
+                if (pr > 0.0f) {
+                    const f3 reflColor = clamp_max3(ctx.kr + ctx.fresnelRef, 1.0f);
+                    const float pdfH = ((a + 1.0f) / (2.0f * PI_F)) * powNoH;
+                    const float pdfDir = pdfH / (4.0f * fmaxf(1e-6f, VoH));
+                    pdfRefl = pdfDir * (pr / total);
+                    const float invVoH = 1.0f / fmaxf(1e-6f, VoH);
+                    fRefl = reflColor * ((a + 8.0f) / (8.0f * PI_F)) * powNoH * invVoH;
+                }
+                if (ps > 0.0f) {
+                    float pdfDir = ((a + 1.0f) / (2.0f * PI_F)) * powNoH;
+                    pdfDir /= (4.0f * fmaxf(1e-6f, VoH));
+                    pdfSpec = pdfDir * (ps / total);
+                    hasSpec = true;
+                    const float invVoH = 1.0f / fmaxf(1e-6f, VoH);
+                    fSpec = ctx.specColor * ((a + 8.0f) / (8.0f * PI_F)) * powNoH * invVoH;
+                }
+            }
+            mult = (fRefl + fDiff + fSpec) * cosN;
+        }
+        pdf = pdfDiff + pdfSpec + pdfRefl;
+        const bool hasRefl = (pdfRefl > 0.0f);
+        if ((hasSpec || hasRefl) && pd > 0.0f) lobe = LOBE_ALL;
+        else if (hasSpec || hasRefl) lobe = LOBE_SPECULAR;
+        else lobe = LOBE_DIFFUSE;
+    } else {
+        const float pr = (max3c(ctx.kr) > 0.0f) ? luma1(ctx.kr + ctx.fresnelRef) : 0.0f;
+        const float total = pd + ps + pr + pt;
+        if (total <= 0.0f) return;
+        if (pt > 0.0f) {
+            const float eta = s.front ? 1.0f / ctx.ior : ctx.ior;
+            const float absCosWo = fabsf(dot3(ctx.N, ctx.V));
+            const float absCosWi = fabsf(dot3(ctx.N, dir));
+            if (absCosWi <= 0.0f || absCosWo <= 0.0f) return;
+            if (phong) {
+                const f3 I = -ctx.V;
+                const float cosI = -dot3(ctx.N, I);
+                const float k = 1.0f - eta * eta * (1.0f - cosI * cosI);
+                if (k < 0.0f) return;
+                const float cosTIdeal = sqrtf(k);
+                const f3 T = safe_normalize3(eta * I + (eta * cosI - cosTIdeal) * ctx.N);
+                const float cosT = fmaxf(0.0f, dot3(T, dir));
+                if (cosT <= 0.0f) return;
+                const float pdfDir = ((a + 1.0f) / (2.0f * PI_F)) * powf(cosT, a);
+                const float etaScale = transmission_scale(eta);
+                const f3 fTrans = ctx.transColor * ((a + 2.0f) / (2.0f * PI_F)) * powf(cosT, a);
+                mult = fTrans * etaScale;
+                pdf = (pt / total) * pdfDir;
+                lobe = LOBE_TRANSMISSION;
+            } else {
+                f3 H = safe_normalize3(ctx.V + dir * eta);
+                if (dot3(ctx.N, H) < 0.0f) H = -H;
+                const float NoH = fmaxf(0.0f, dot3(ctx.N, H));
+                if (NoH <= 0.0f) return;
+                const float VoH = dot3(ctx.V, H);
+                const float WiH = dot3(dir, H);
+                if (VoH * WiH >= 0.0f) return;
+                const float denom = eta * VoH + WiH;
+                if (fabsf(denom) <= 1e-6f) return;
+                const float pdfH = ((a + 1.0f) / (2.0f * PI_F)) * powf(NoH, a);
+                const float dwh_dwi = fabsf((eta * eta * WiH) / (denom * denom));
+                const float pdfDir = pdfH * dwh_dwi;
+                const float etaScale = transmission_scale(eta);
+                const f3 fTrans = ctx.transColor * ((a + 2.0f) / (2.0f * PI_F)) * powf(NoH, a);
+                const float factor = fabsf(WiH * VoH) / fmaxf(1e-6f, absCosWo * denom * denom);
+                mult = fTrans * etaScale * factor;
+                pdf = (pt / total) * pdfDir;
+                lobe = LOBE_TRANSMISSION;
+            }
+        }
+    }
+    if (pdf <= 0.0f || max3c(mult) <= 0.0f) return;
+    si.mult = mult;
+    si.prob = pdf;
+    si.dist = 0.0f;
+    si.lobe = lobe;
+}
+
+// ---- PointLight -------------------------------------------------------------------------------------------
+// Shading.cpp:118-165
+__device__ __forceinline__ bool light_generate_sample(const DevLight& L, f3 P, float u1, float u2, f3& dir, DirInfo& si) {
+    set_void(si);
+    const f3 position = ld3(L.pos), intensity = ld3(L.intensity);
+    const f3 toC = position - P;
+    const float dc = len3(toC);
+    if (dc < 1e-6f) return false;
+    if (L.size <= 0.0f) {
+        dir = toC / dc;
+        const float att_factor = (L.attenuation == 0.0f) ? 1.0f : L.attenuation * L.attenuation;
+        si.mult = intensity / (att_factor * dc * dc);
+        si.prob = 1.0f;
+        si.dist = dc;
+        si.lobe = LOBE_ALL;
+        return true;
+    }
+    const float z = 1.0f - 2.0f * u1;
+    const float rxy = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    const float phi = 2.0f * PI_F * u2;
+    const f3 onS = mk3(rxy * cosf(phi), rxy * sinf(phi), z);
+    const f3 Lpos = position + L.size * onS;
+    const f3 wi = Lpos - P;
+    const float dist = len3(wi);
+    if (dist < 1e-6f) return false;
+    dir = wi / dist;
+    const float cosLight = fmaxf(0.0f, dot3(-onS, dir));
+    if (cosLight <= 0.0f) return false;
+    const float area = 4.0f * PI_F * L.size * L.size;
+    const float pdfArea = 2.0f / area;
+    const f3 radiance = intensity / (PI_F * L.size * L.size);
+    const float att_factor = (L.attenuation == 0.0f) ? 1.0f : L.attenuation * L.attenuation;
+    si.mult = radiance / att_factor;
+    si.prob = pdfArea;
+    si.dist = dist;
+    si.lobe = LOBE_ALL;
+    return si.prob > 0.0f;
+}
+
+// Shading.cpp:167-209
+__device__ __forceinline__ void light_get_sample_info(const DevLight& L, f3 P, f3 dirIn, DirInfo& si) {
+    set_void(si);
+    const f3 position = ld3(L.pos), intensity = ld3(L.intensity);
+    const f3 d = safe_normalize3(dirIn);
+    if (L.size <= 0.0f) {
+        const f3 toL = position - P;
+        const float dist = len3(toL);
+        if (dist < 1e-6f) return;
+        if (dot3(safe_normalize3(toL), d) < 1.0f - 1e-4f) return;
+        const float att_factor = (L.attenuation == 0.0f) ? 1.0f : L.attenuation * L.attenuation;
+        si.mult = intensity / (att_factor * dist * dist);
+        si.prob = 1.0f;
+        si.dist = dist;
+        si.lobe = LOBE_ALL;
+        return;
+    }
+    const f3 oc = P - position;
+    const float b = dot3(oc, d);
+    const float c = len2_3(oc) - L.size * L.size;
+    const float disc = b * b - c;
+    if (disc < 0.0f) return;
+    const float t = -b - sqrtf(fmaxf(0.0f, disc));
+    if (t <= 1e-6f) return;
+    const f3 hit = P + d * t;
+    const f3 nL = safe_normalize3(hit - position);
+    const float cosLight = fmaxf(0.0f, dot3(-nL, d));
+    if (cosLight <= 0.0f) return;
+    const float area = 4.0f * PI_F * L.size * L.size;
+    const float pdfArea = 2.0f / area;
+    const f3 radiance = intensity / (PI_F * L.size * L.size);
+    const float att_factor = (L.attenuation == 0.0f) ? 1.0f : L.attenuation * L.attenuation;
+    si.mult = radiance / att_factor;
+    si.prob = pdfArea;
+    si.dist = t;
+    si.lobe = LOBE_ALL;
+}
+
+// PointLight::IntersectRay normal for the MIS term of NEE (RayCaster.cpp:482-486): returns cosLight or 1 on miss
+__device__ __forceinline__ float light_cos_for_nee(const DevLight& L, f3 P, f3 d) {
+    if (L.size <= 0.0f) return 1.0f;
+    const f3 position = ld3(L.pos);
+    const f3 oc = P - position;
+    const float b = dot3(oc, d);
+    const float c = len2_3(oc) - L.size * L.size;
+    const float disc = b * b - c;
+    if (disc < 0.0f) return 1.0f;
+    float t = -b - sqrtf(fmaxf(0.0f, disc));
+    if (t < 0.0f) t = -b + sqrtf(fmaxf(0.0f, disc));
+    if (t < 0.0f) return 1.0f;
+    const f3 hp = P + d * t;
+    const f3 N = safe_normalize3(hp - position);
+    // HIT_FRONT passed by the caller is ignored by PointLight::IntersectRay (Shading.cpp:65-86)
+    return fmaxf(0.0f, dot3(-N, d));
+}
+
+// Shading.cpp:88-116
+__device__ __forceinline__ void light_random_photon(const DevLight& L, const float u[4], f3& rp, f3& rd, f3& c) {
+    const f3 position = ld3(L.pos);
+    f3 pos = position;
+    int k = 0;
+    if (L.size > 0.0f) {
+        const float u1 = u[k++];
+        const float u2 = u[k++];
+        const float z = 1.0f - 2.0f * u1;
+        const float rxy = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+        const float phi = 2.0f * PI_F * u2;
+        pos = position + L.size * mk3(rxy * cosf(phi), rxy * sinf(phi), z);
+    }
+    const float u1 = u[k++];
+    const float u2 = u[k++];
+    const float z = 1.0f - 2.0f * u1;
+    const float rxy = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    const float phi = 2.0f * PI_F * u2;
+    f3 dir = mk3(rxy * cosf(phi), rxy * sinf(phi), z);
+    if (L.size > 0.0f) {
+        const f3 n = safe_normalize3(pos - position);
+        if (dot3(dir, n) < 0.0f) dir = -dir;
+    }
+    rp = pos;
+    rd = dir;
+    c = ld3(L.intensity) * 4.0f * PI_F;
+}

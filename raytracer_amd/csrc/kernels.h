@@ -27,7 +27,7 @@ struct LaunchCfg {
 
 // extend: closest hit for n rays (rtx_ray layout, 2 x float4) -> hits float4 {t,u,v,bits(slot)}
 void launch_extend(const DevScene& sc, const LaunchCfg& cfg, const float4* rays, uint32_t n, int hitSide, int withLights,
-                   float4* hits);
+                   float4* hits, const uint32_t* queue = nullptr);
 // CameraAdapter.h:7-27 pixel-centre rays for the whole image
 void launch_primary_raygen(const DevCamera& cam, float4* rays, hipStream_t stream);
 // compact hit -> full rtx_hit (device array)
@@ -38,3 +38,22 @@ void launch_visibility(const DevScene& sc, const LaunchCfg& cfg, const float4* r
                        int useTransmittance, float* vis, unsigned long long* hopCounter);
 
 int query_resident_blocks(int which);  // blocks per CU for kernel 'which' (0 extend, 1 shadow)
+
+// ---- wavefront path tracing (kernels_path.hip) ----
+struct PathPool;
+struct DevPhotonMap;
+void launch_raygen(const DevCamera& cam, const PathPool& pool, const int* pixels, uint32_t nPix, int S, int sBase, int indexStride,
+                   uint32_t* queueOut, uint32_t* counters, hipStream_t stream);
+void launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm, const uint32_t* queueIn,
+                  uint32_t n, int bounce, int maxBounces, unsigned long long seed, int sBase, int S, const int* pixels,
+                  uint32_t* queueOut, uint32_t* counters, hipStream_t stream);
+void launch_shadow(const DevScene& sc, const LaunchCfg& cfg, const PathPool& pool, uint32_t n, int useTransmittance);
+void launch_resolve(const PathPool& pool, const uint32_t* queueIn, uint32_t n, int nLights, int usePhotons, hipStream_t stream);
+void launch_film(const PathPool& pool, const rtx_film& film, const int* pixels, uint32_t nPix, int S, int W, int H, int filterType,
+                 float filterRadius, int resetZ, float4* samplesOut, int sBase, int sppTotal, hipStream_t stream);
+void launch_adaptive(const PathPool& pool, const int* pixels, uint32_t nPix, float maxHalf, int sppMax, int* pixelsNext,
+                     uint32_t* counter, hipStream_t stream);
+void launch_fill_int(int* p, uint32_t n, int v, hipStream_t stream);
+void launch_film_clear(const rtx_film& film, uint32_t n, hipStream_t stream);
+void launch_stats_clear(const PathPool& pool, uint32_t n, hipStream_t stream);
+void launch_film_resolve(const rtx_film& film, uint32_t n, int srgb, float* linear, unsigned char* rgb8, hipStream_t stream);

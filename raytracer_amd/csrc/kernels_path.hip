@@ -1,1 +1,667 @@
+// Wavefront path tracing on gfx950: ray generation, shade, shadow, NEE resolve, film accumulation and adaptive
+// refinement. Together with the extend kernel (kernels_trace.hip) these replace RayCaster::RenderBucket +
+// TracePath (reference RayTracer/RayCaster.cpp:339-574, 697-1023). Kernels are connected by index queues in HBM
+// that are compacted with wave64 ballot / mbcnt prefix sums (one atomic per wave).
 #include "kernels.h"
+#include "pathstate.h"
+#include "bsdf.h"
+#include "shadow.h"
+#include "photon_gather.h"
+
+// ---- wave-level queue append -------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
+    const unsigned long long mask = __ballot(pred);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total = (uint32_t)__popcll(mask);
+    uint32_t base = 0;
+    if (total) {
+        const int leader = __ffsll((long long)mask) - 1;
+        if ((int)lane == leader) base = atomicAdd(counter, total);
+        base = __shfl(base, leader);
+    }
+    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    return base + prefix;
+}
+
+// ---- sampler (RayCaster.cpp:65-81, 784-796, 729-762) --------------------------------------------------------
+template <int BASE>
+__device__ __forceinline__ float halton(int index) {
+    float r = 0.0f;
+    float f = 1.0f / (float)BASE;
+    for (int i = index; i > 0; i /= BASE) {
+        r += f * (float)(i % BASE);
+        f /= (float)BASE;
+    }
+    return r;
+}
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long& x) {
+    unsigned long long z = (x += 0x9e3779b97f4a7c15ULL);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ void pixel_shifts(int x, int y, float& sx, float& sy) {
+    unsigned long long s = ((unsigned long long)(uint32_t)x << 32) | (unsigned long long)(uint32_t)y;
+    const unsigned long long h1 = splitmix64(s);
+    const unsigned long long h2 = splitmix64(s);
+    sx = (float)((double)(h1 & 0xFFFFFFFFULL) / 4294967296.0);
+    sy = (float)((double)(h2 & 0xFFFFFFFFULL) / 4294967296.0);
+}
+
+__global__ void raygen_kernel(DevCamera cam, PathPool pool, const int* __restrict__ pixels, uint32_t nPix, int S, int sBase,
+                              int indexStride, uint32_t* __restrict__ queueOut, uint32_t* counters) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nSlots = nPix * (uint32_t)S;
+    bool valid = false;
+    if (slot < nSlots) {
+        const uint32_t lane = slot & 63u;
+        const uint32_t cs = slot >> 6;
+        const uint32_t chunk = cs / (uint32_t)S, sIn = cs % (uint32_t)S;
+        const int pix = pixels[chunk * 64u + lane];
+        if (pix >= 0) {
+            valid = true;
+            const int x = pix % cam.W, y = pix / cam.W;
+            const int s = sBase + (int)sIn;
+            float shiftX, shiftY;
+            pixel_shifts(x, y, shiftX, shiftY);
+            const int sampleIndex = pix * indexStride + (s + 1);
+            const float hx = halton<2>(sampleIndex);
+            const float hy = halton<3>(sampleIndex);
+            float jx = hx + shiftX;
+            float jy = hy + shiftY;
+            jx = fmodf(jx, 1.0f) - 0.5f;
+            jy = fmodf(jy, 1.0f) - 0.5f;
+            const float samplePosX = (float)x + 0.5f + jx;
+            const float samplePosY = (float)y + 0.5f + jy;
+            const float ndcY = 1.0f - (samplePosY / (float)cam.H) * 2.0f;
+            const float sy = ndcY * cam.halfY;
+            const float ndcX = (samplePosX / (float)cam.W) * 2.0f - 1.0f;
+            const float sx = ndcX * cam.halfX;
+            const f3 r = ld3(cam.r), u = ld3(cam.u), f = ld3(cam.f), pos = ld3(cam.pos);
+            const f3 dirVec = r * sx + u * sy + f;
+            f3 ro, rd;
+            if (cam.thinLens) {
+                const f3 pixelWorld = pos + dirVec * cam.focus;
+                const float lx = halton<5>(sampleIndex);
+                const float ly = halton<7>(sampleIndex);
+                const float rdisk = sqrtf(lx);
+                const float theta = 2.0f * PI_F * ly;
+                const float dx = rdisk * cosf(theta);
+                const float dy = rdisk * sinf(theta);
+                const f3 lensPoint = pos + r * (dx * cam.aperture) + u * (dy * cam.aperture);
+                ro = lensPoint;
+                rd = normalized3(pixelWorld - lensPoint);
+            } else {
+                ro = pos;
+                rd = normalized3(dirVec);
+            }
+            pool.rays[2 * (size_t)slot] = make_float4(ro.x, ro.y, ro.z, RTX_BIG);
+            pool.rays[2 * (size_t)slot + 1] = make_float4(rd.x, rd.y, rd.z, 0.0f);
+            pool.L[slot] = make_float4(0.0f, 0.0f, 0.0f, RTX_BIG);
+            pool.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            pool.medium[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(PF_LAST_DELTA));
+            pool.albedo[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            pool.normal[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            pool.samplePos[slot] = make_float2(samplePosX, samplePosY);
+        }
+    }
+    const uint32_t q = wave_append(valid, &counters[0]);
+    if (valid) queueOut[q] = slot;
+}
+
+// ---- shade ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f3 apply_absorption(f3 c, f3 absorption, float dist) {   // RayCaster.cpp:281-301
+    if (dist <= 0.0f) return c;
+    if (absorption.x == 0.0f && absorption.y == 0.0f && absorption.z == 0.0f) return c;
+    const float ar = expf(-fmaxf(0.0f, absorption.x) * dist);
+    const float ag = expf(-fmaxf(0.0f, absorption.y) * dist);
+    const float ab = expf(-fmaxf(0.0f, absorption.z) * dist);
+    return mk3(fminf(c.x, c.x * ar), fminf(c.y, c.y * ag), fminf(c.z, c.z * ab));
+}
+__device__ __forceinline__ void dir_to_screen_uv(const DevCamera& cam, f3 dir, float& u, float& v) {   // :303-330
+    const f3 f = ld3(cam.f), r = ld3(cam.r), uvec = ld3(cam.u);
+    float dz = dot3(dir, f);
+    if (fabsf(dz) < 1e-6f) dz = (dz >= 0.0f) ? 1e-6f : -1e-6f;
+    const float sx = dot3(dir, r) / dz;
+    const float sy = dot3(dir, uvec) / dz;
+    const float fovRad = cam.fov * PI_F / 180.0f;
+    const float halfY = tanf(0.5f * fovRad);
+    const float aspect = (cam.H > 0) ? (float)cam.W / (float)cam.H : 1.0f;
+    const float halfX = halfY * aspect;
+    const float ndcX = sx / halfX;
+    const float ndcY = sy / halfY;
+    u = (ndcX + 1.0f) * 0.5f;
+    v = (1.0f - ndcY) * 0.5f;
+    u = u - floorf(u);
+    v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+}
+__device__ __forceinline__ float power_heuristic(float pdfA, float pdfB) {   // :102-106
+    const float a = pdfA * pdfA;
+    const float b = pdfB * pdfB;
+    return a / (a + b);
+}
+__device__ __forceinline__ bool has_map_or_value(const float* c, int tex) {   // :333-337
+    return tex >= 0 || c[0] != 0.0f || c[1] != 0.0f || c[2] != 0.0f;
+}
+
+
+// One bounce of TracePath (RayCaster.cpp:359-567) for every path in queueIn. Paths that continue are appended to
+// queueOut; NEE shadow segments are appended to the shadow queue; their results are folded in by resolve_kernel.
+__global__ __launch_bounds__(256) void shade_kernel(DevScene sc, DevCamera cam, PathPool pool, DevPhotonMap pm,
+                                                    const uint32_t* __restrict__ queueIn, uint32_t n, int bounce,
+                                                    int maxBounces, unsigned long long seed, int sBase, int S,
+                                                    const int* __restrict__ pixels, uint32_t* __restrict__ queueOut,
+                                                    uint32_t* counters) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool alive = false;
+    uint32_t slot = 0;
+    const uint32_t cap = pool.capacity;
+    if (i < n) {
+        slot = queueIn[i];
+        const float4 ra = pool.rays[2 * (size_t)slot], rb = pool.rays[2 * (size_t)slot + 1];
+        const float4 hv = pool.hits[slot];
+        RayT ray{ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, ra.w};
+        HitT h{hv.x, hv.y, hv.z, __float_as_int(hv.w)};
+        float4 L4 = pool.L[slot];
+        float4 b4 = pool.beta[slot];
+        float4 m4 = pool.medium[slot];
+        f3 L = mk3(L4.x, L4.y, L4.z);
+        f3 beta = mk3(b4.x, b4.y, b4.z);
+        float lastPdf = b4.w;
+        uint32_t flags = __float_as_uint(m4.w);
+        f3 mediumAbs = mk3(m4.x, m4.y, m4.z);
+        const f3 rdir = mk3(ray.dx, ray.dy, ray.dz), rorg = mk3(ray.ox, ray.oy, ray.oz);
+        // pixel / sample of this slot -> RNG key
+        const uint32_t lane64 = slot & 63u, cs = slot >> 6;
+        const int pix = pixels[(cs / (uint32_t)S) * 64u + lane64];
+        const int sIdx = sBase + (int)(cs % (uint32_t)S);
+        bool pending = false;   // NEE of this bounce to be resolved
+
+        do {
+            if (h.slot == -1) {
+                // ---- miss: backplate / environment (RayCaster.cpp:362-382) ----
+                const f3 nd = normalized3(rdir);
+                float uEnv = 0.0f, vEnv = 0.0f;
+                dir_to_screen_uv(cam, nd, uEnv, vEnv);
+                const bool hasBackground = has_map_or_value(sc.bg, sc.bg_tex);
+                const bool hasEnvironment = has_map_or_value(sc.env, sc.env_tex);
+                const f3 backplate = hasBackground ? eval_tc(sc, sc.bg, sc.bg_tex, mk3(uEnv, vEnv, 0.0f)) : mk3(0.0f);
+                f3 envLight = mk3(0.0f);
+                if (hasEnvironment) envLight = sc.env_tex >= 0 ? ld3(sc.env) * tex_eval_env(sc, sc.env_tex, nd) : ld3(sc.env);
+                const f3 bgEmit = (hasBackground && sc.bg_emission > 0.0f) ? backplate * sc.bg_emission : mk3(0.0f);
+                if (bounce == 0) {
+                    const f3 vis = hasBackground ? backplate : envLight;
+                    L = L + beta * (vis + bgEmit);
+                } else {
+                    L = L + beta * (envLight + bgEmit);
+                }
+                break;
+            }
+            SurfHit sh;
+            if (h.slot >= 0) resolve_triangle(sc, ray, h, sh);
+            else resolve_light(sc, ray, h, sh);
+            const float hitDist = len3(sh.p - rorg);
+            if ((flags & PF_INSIDE_MEDIUM) && hitDist > 0.0f) beta = apply_absorption(beta, mediumAbs, hitDist);
+
+            const DevMaterial* mtl = nullptr;
+            if (sh.obj >= 0) {
+                const int mi = sc.objs[sh.obj].material;
+                if (mi >= 0) mtl = &sc.mtls[mi];
+            }
+            if (mtl) apply_bump(sc, *mtl, sh);
+            SampCtx sx;
+            sx.P = sh.p;
+            sx.V = -normalized3(rdir);
+            sx.N = sh.N;
+            sx.GN = sh.GN;
+            sx.uvw = sh.uvw;
+            sx.front = sh.front;
+            sx.key = rng_key(seed, (uint32_t)pix, (uint32_t)sIdx);
+            sx.stream = (uint32_t)bounce;
+
+            if (bounce == 0) {   // :401-407
+                L4.w = hitDist;
+                const f3 alb = mtl ? eval_tc(sc, mtl->kd, mtl->kd_tex, sx.uvw) : mk3(0.5f);
+                const f3 fn = safe_normalize3(sh.GN);
+                pool.albedo[slot] = make_float4(alb.x, alb.y, alb.z, 1.0f);
+                pool.normal[slot] = make_float4(fn.x, fn.y, fn.z, 1.0f);
+            }
+
+            if (sh.light >= 0) {   // :410-439
+                const DevLight& light = sc.lights[sh.light];
+                const f3 emitted = ld3(light.intensity) / (PI_F * light.size * light.size);
+                float lightPdfSA = 0.0f;
+                if (flags & PF_HAS_PREV) {
+                    const float4 pp = pool.prevP[slot];
+                    DirInfo li;
+                    light_get_sample_info(light, mk3(pp.x, pp.y, pp.z), rdir, li);
+                    lightPdfSA = li.prob;
+                    if (light.size > 0.0f) {
+                        const float cosLight = fmaxf(0.0f, dot3(-sh.N, safe_normalize3(rdir)));
+                        const float dist2 = li.dist * li.dist;
+                        if (cosLight > 1e-6f && dist2 > 0.0f) lightPdfSA = li.prob * dist2 / cosLight;
+                        else lightPdfSA = 0.0f;
+                    } else
+                        lightPdfSA = 0.0f;
+                }
+                const float w = ((flags & PF_LAST_DELTA) || lightPdfSA <= 0.0f) ? 1.0f : power_heuristic(lastPdf, lightPdfSA);
+                L = L + beta * emitted * w;
+                break;
+            }
+            if (!mtl) break;
+
+            const f3 emission = eval_tc(sc, mtl->ke, mtl->ke_tex, sx.uvw);   // :445-446
+            if (max3c(emission) > 0.0f) L = L + beta * emission;
+
+            const PhongCtx ctx = build_phong_ctx(sc, *mtl, sx);
+            const bool phong = mtl->type == RTX_MTL_PHONG;
+
+            // ---- next event estimation: contributions now, visibility by the shadow kernel (:456-503) ----
+            const bool photonSurface = (mtl->kd[0] + mtl->kd[1] + mtl->kd[2]) > 0.0f;
+            const bool wantCaustic = pm.n > 0 && photonSurface;
+            for (int l = 0; l < sc.n_lights; ++l) {
+                const DevLight& light = sc.lights[l];
+                f3 ldir;
+                DirInfo li;
+                float4 contrib = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+                const float u1 = sx.rnd(DIM_LIGHT0 + 2 * l), u2 = sx.rnd(DIM_LIGHT0 + 2 * l + 1);
+                if (light_generate_sample(light, sx.P, u1, u2, ldir, li) && li.prob > 0.0f && max3c(li.mult) > 0.0f) {
+                    const float shadowMax = (li.dist > 0.0f && li.dist < RTX_BIG * 0.5f) ? li.dist : RTX_BIG;
+                    DirInfo bs;
+                    evaluate_phong_blinn(ctx, phong, sx, safe_normalize3(ldir), bs);
+                    f3 c = mk3(0.0f);
+                    if (bs.prob > 0.0f && max3c(bs.mult) > 0.0f) {
+                        if (light.size > 0.0f) {
+                            const float dist = li.dist;
+                            const float cosLight = light_cos_for_nee(light, sh.p, safe_normalize3(ldir));
+                            const float pdfSolidAngle = (cosLight > 1e-6f && dist > 1e-6f) ? li.prob * dist * dist / cosLight : 0.0f;
+                            if (pdfSolidAngle > 0.0f) {
+                                const float w = power_heuristic(pdfSolidAngle, bs.prob);
+                                const float G = 1.0f / fmaxf(1e-6f, dist * dist);
+                                c = li.mult * bs.mult * G * (w / fmaxf(1e-6f, li.prob));
+                            }
+                        } else {
+                            const float w = power_heuristic(li.prob, bs.prob);
+                            c = li.mult * bs.mult * (w / fmaxf(1e-4f, li.prob));
+                        }
+                    }
+                    // the shadow segment is needed when it can contribute, or when its visibility scales the
+                    // caustic term (:468, :518)
+                    if (max3c(c) > 0.0f || wantCaustic) {
+                        contrib = make_float4(c.x, c.y, c.z, 0.0f);
+                        pending = true;
+                        // wave-wide append of the lanes that reach this point (ballot counts active lanes only)
+                        const uint32_t qs = wave_append(true, &counters[1]);
+                        const f3 so = offset_point(sh.p, sx.GN, ldir);
+                        const f3 sd = safe_normalize3(ldir);
+                        pool.shadowQ[2 * (size_t)qs] = make_float4(so.x, so.y, so.z, shadowMax);
+                        pool.shadowQ[2 * (size_t)qs + 1] = make_float4(sd.x, sd.y, sd.z, __uint_as_float(slot * 8u + (uint32_t)l));
+                    }
+                }
+                pool.nee[(size_t)l * cap + slot] = contrib;
+            }
+            if (pending) pool.pendBeta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
+
+            if (pm.n > 0) {   // :508-522 (scaled by the visibility in resolve_kernel)
+                float4 cz = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (photonSurface) {
+                    f3 irrad = estimate_irradiance(pm, sh.p, sh.N);
+                    if (max3c(irrad) > 0.0f) {
+                        const f3 kd = eval_tc(sc, mtl->kd, mtl->kd_tex, sx.uvw);
+                        irrad = irrad * 0.1f;   // kCausticBoost
+                        const f3 t = kd * (1.0f / PI_F) * irrad;
+                        cz = make_float4(t.x, t.y, t.z, 1.0f);
+                        if (!pending) pool.pendBeta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
+                        pending = true;
+                    }
+                }
+                pool.caustic[slot] = cz;
+            }
+
+            // ---- BSDF sampling for the next bounce (:525-566) ----
+            f3 nextDir;
+            DirInfo bsd;
+            if (!sample_phong_blinn(ctx, phong, sx, nextDir, bsd)) break;
+            if (bsd.prob <= 0.0f || max3c(bsd.mult) <= 0.0f) break;
+            const float pdfThroughput = fmaxf(1e-4f, bsd.prob);
+            beta = beta * (bsd.mult / pdfThroughput);
+            lastPdf = bsd.prob;
+            flags = (flags & ~PF_LAST_DELTA) | (bsd.dist < 0.0f ? PF_LAST_DELTA : 0u);
+            pool.prevP[slot] = make_float4(sh.p.x, sh.p.y, sh.p.z, 0.0f);
+            flags |= PF_HAS_PREV;
+            if (bsd.lobe & LOBE_TRANSMISSION) {
+                if (sx.front) {
+                    flags |= PF_INSIDE_MEDIUM;
+                    mediumAbs = ld3(mtl->absorption);
+                } else {
+                    flags &= ~PF_INSIDE_MEDIUM;
+                    mediumAbs = mk3(0.0f);
+                }
+            }
+            if (bounce >= 5) {
+                float q = clamp01f(max3c(beta));
+                q = fmaxf(q, 0.05f);
+                if (sx.rnd(DIM_RR) > q) break;
+                beta = beta * (1.0f / q);
+            }
+            if (bounce + 1 >= maxBounces) break;
+            const f3 no = offset_point(sh.p, sx.GN, nextDir);
+            const f3 nd = safe_normalize3(nextDir);
+            pool.rays[2 * (size_t)slot] = make_float4(no.x, no.y, no.z, RTX_BIG);
+            pool.rays[2 * (size_t)slot + 1] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+            alive = true;
+        } while (false);
+
+        pool.L[slot] = make_float4(L.x, L.y, L.z, L4.w);
+        pool.beta[slot] = make_float4(beta.x, beta.y, beta.z, lastPdf);
+        pool.medium[slot] = make_float4(mediumAbs.x, mediumAbs.y, mediumAbs.z, __uint_as_float(flags));
+        if (!pending) {
+            // mark "nothing to resolve" for resolve_kernel
+            pool.pendBeta[slot] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+        }
+    }
+    // ---- surviving paths -> next queue ----
+    const uint32_t q = wave_append(alive, &counters[0]);
+    if (alive) queueOut[q] = slot;
+}
+
+// ---- shadow --------------------------------------------------------------------------------------------------
+// Visible() for every queued NEE segment (RayCaster.cpp:465): writes the transmittance next to its contribution.
+__global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene sc, PathPool pool, uint32_t n, int useTransmittance,
+                                                            uint32_t* workCounter, uint2* spill) {
+    __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    TravStack st{&lds_stack[threadIdx.x], spill + gtid, gridDim.x * blockDim.x};
+    uint32_t hops = 0, nc = 0, tc = 0;
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(workCounter, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n) break;
+        const uint32_t i = base + lane;
+        if (i < n) {
+            const float4 a = pool.shadowQ[2 * (size_t)i], b = pool.shadowQ[2 * (size_t)i + 1];
+            const uint32_t code = __float_as_uint(b.w);
+            const uint32_t slot = code >> 3, l = code & 7u;
+            const float T = visible_chain_from<false>(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, useTransmittance != 0, st,
+                                                      &hops, &nc, &tc);
+            pool.nee[(size_t)l * pool.capacity + slot].w = T;
+        }
+    }
+    atomicAdd(&pool.rayCounters[0], (unsigned long long)hops);
+}
+
+// ---- resolve: L += beta * sum_i c_i T_i  and the caustic term (RayCaster.cpp:470-522) ------------------------
+__global__ void resolve_kernel(PathPool pool, const uint32_t* __restrict__ queueIn, uint32_t n, int nLights, int usePhotons) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = queueIn[i];
+    const float4 pb = pool.pendBeta[slot];
+    if (pb.w < 0.0f) return;
+    const f3 beta = mk3(pb.x, pb.y, pb.z);
+    float4 L4 = pool.L[slot];
+    f3 L = mk3(L4.x, L4.y, L4.z);
+    f3 direct = mk3(0.0f);
+    float maxVisibility = 0.0f;
+    for (int l = 0; l < nLights; ++l) {
+        const float4 c = pool.nee[(size_t)l * pool.capacity + slot];
+        if (c.w < 0.0f) continue;
+        maxVisibility = fmaxf(maxVisibility, c.w);
+        if (c.w <= 0.0f) continue;
+        direct = direct + mk3(c.x, c.y, c.z) * c.w;
+    }
+    if (max3c(direct) > 0.0f) L = L + beta * direct;
+    if (usePhotons) {
+        const float4 cz = pool.caustic[slot];
+        if (cz.w > 0.0f) {
+            const float causticScale = 0.1f + 0.9f * maxVisibility;
+            L = L + beta * (mk3(cz.x, cz.y, cz.z) * causticScale);
+        }
+    }
+    pool.L[slot] = make_float4(L.x, L.y, L.z, L4.w);
+}
+
+// ---- film (RayCaster.cpp:798-838) -----------------------------------------------------------------------------
+__device__ __forceinline__ float filter_radius(int type, float radiusOverride) {   // :84-92, :807
+    if (radiusOverride > 0.0f) return radiusOverride;
+    switch (type) {
+        case RTX_FILTER_GAUSSIAN: return 1.5f;
+        case RTX_FILTER_MITCHELL: return 2.0f;
+        case RTX_FILTER_LANCZOS: return 2.0f;
+        default: return 1.0f;
+    }
+}
+__device__ __forceinline__ float filter1d(int type, float radius, float x) {   // :643-690
+    switch (type) {
+        case RTX_FILTER_GAUSSIAN: {
+            float sigma = radius * 0.5f;
+            if (sigma <= 0.0f) sigma = 0.5f;
+            const float t = x / sigma;
+            return expf(-0.5f * t * t);
+        }
+        case RTX_FILTER_MITCHELL: {
+            const float B = 1.0f / 3.0f;
+            const float C = 1.0f / 3.0f;
+            x = fabsf(x);
+            if (x < 1.0f)
+                return ((12.0f - 9.0f * B - 6.0f * C) * x * x * x + (-18.0f + 12.0f * B + 6.0f * C) * x * x + (6.0f - 2.0f * B)) / 6.0f;
+            else if (x < 2.0f)
+                return ((-B - 6.0f * C) * x * x * x + (6.0f * B + 30.0f * C) * x * x + (-12.0f * B - 48.0f * C) * x + (8.0f * B + 24.0f * C)) / 6.0f;
+            return 0.0f;
+        }
+        case RTX_FILTER_LANCZOS: {
+            const float a = radius;
+            x = fabsf(x);
+            if (x >= a) return 0.0f;
+            if (x < 1e-6f) return 1.0f;
+            const float pix = PI_F * x;
+            return (a * sinf(pix) * sinf(pix / a)) / (pix * pix);
+        }
+        default: {
+            x = fabsf(x);
+            if (x >= radius) return 0.0f;
+            return 1.0f - x / radius;
+        }
+    }
+}
+
+// One lane per pixel of the pass: walks its S samples in sample order (so per-pixel sums and the running z are
+// accumulated in the reference's order) and splats them into the film with float atomics.
+__global__ void film_kernel(PathPool pool, rtx_film film, const int* __restrict__ pixels, uint32_t nPix, int S, int W, int H,
+                            int filterType, float filterRadius, int resetZ, float4* __restrict__ samplesOut, int sBase,
+                            int sppTotal) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nPix) return;
+    const int pix = pixels[i];
+    if (pix < 0) return;
+    const uint32_t chunk = i >> 6, lane = i & 63u;
+    float4 s1 = pool.statSum[pix];
+    float4 s2 = pool.statSum2[pix];
+    int n = __float_as_int(s1.w);
+    float bestZ = resetZ ? RTX_BIG : s2.w;
+    const float radius = filter_radius(filterType, filterRadius);
+    int cnt = film.count[pix];
+    bool guide = film.albedo ? (film.albedo[4 * (size_t)pix + 3] != 0.0f) : true;
+    for (int s = 0; s < S; ++s) {
+        const uint32_t slot = (chunk * (uint32_t)S + (uint32_t)s) * 64u + lane;
+        const float4 L4 = pool.L[slot];
+        // kRadianceClamp (RayCaster.cpp:569-571)
+        const float cr = fminf(L4.x, 10.0f), cg = fminf(L4.y, 10.0f), cb = fminf(L4.z, 10.0f);
+        if (samplesOut) samplesOut[(size_t)pix * sppTotal + sBase + s] = make_float4(cr, cg, cb, L4.w);
+        if (L4.w < bestZ) bestZ = L4.w;
+        cnt += 1;
+        if (!guide) {
+            const float4 al = pool.albedo[slot];
+            if (al.w != 0.0f) {
+                guide = true;
+                const float4 nn = pool.normal[slot];
+                float* A = film.albedo + 4 * (size_t)pix;
+                A[0] = al.x; A[1] = al.y; A[2] = al.z; A[3] = 1.0f;
+                if (film.normal) {
+                    float* Nn = film.normal + 4 * (size_t)pix;
+                    Nn[0] = nn.x; Nn[1] = nn.y; Nn[2] = nn.z; Nn[3] = 1.0f;
+                }
+            }
+        }
+        const float2 sp = pool.samplePos[slot];
+        const int x0 = max(0, (int)floorf(sp.x - radius));
+        const int x1 = min(W - 1, (int)ceilf(sp.x + radius));
+        const int y0 = max(0, (int)floorf(sp.y - radius));
+        const int y1 = min(H - 1, (int)ceilf(sp.y + radius));
+        for (int yy = y0; yy <= y1; ++yy) {
+            const float wy = filter1d(filterType, radius, (float)yy + 0.5f - sp.y);
+            if (wy <= 0.0f) continue;
+            for (int xx = x0; xx <= x1; ++xx) {
+                const float wx = filter1d(filterType, radius, (float)xx + 0.5f - sp.x);
+                if (wx <= 0.0f) continue;
+                const float w = wx * wy;
+                const size_t idx = (size_t)yy * W + xx;
+                atomicAdd(&film.accum[4 * idx + 0], cr * w);
+                atomicAdd(&film.accum[4 * idx + 1], cg * w);
+                atomicAdd(&film.accum[4 * idx + 2], cb * w);
+                atomicAdd(&film.accum[4 * idx + 3], w);
+                atomicMin(reinterpret_cast<int*>(&film.z[idx]), __float_as_int(bestZ));   // z >= 0: int order == float order
+            }
+        }
+        n += 1;
+        s1.x += cr; s1.y += cg; s1.z += cb;
+        s2.x += cr * cr; s2.y += cg * cg; s2.z += cb * cb;
+    }
+    film.count[pix] = cnt;
+    s1.w = __int_as_float(n);
+    s2.w = bestZ;
+    pool.statSum[pix] = s1;
+    pool.statSum2[pix] = s2;
+}
+
+// Confidence-interval test (RayCaster.cpp:848-868 / :957-975): pixels that still need samples go to the next list.
+__global__ void adaptive_kernel(PathPool pool, const int* __restrict__ pixels, uint32_t nPix, float maxHalf, int sppMax,
+                                int* __restrict__ pixelsNext, uint32_t* counter) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool refine = false;
+    int pix = -1;
+    if (i < nPix) {
+        pix = pixels[i];
+        if (pix >= 0) {
+            const float4 s1 = pool.statSum[pix], s2 = pool.statSum2[pix];
+            const int n = __float_as_int(s1.w);
+            if (n > 1 && n < sppMax) {
+                const float fn = (float)n;
+                const float meanR = s1.x / fn, meanG = s1.y / fn, meanB = s1.z / fn;
+                const float varR = s2.x / fn - meanR * meanR;
+                const float varG = s2.y / fn - meanG * meanG;
+                const float varB = s2.z / fn - meanB * meanB;
+                float vm = fmaxf(varR, fmaxf(varG, varB));
+                if (vm < 0.0f) vm = 0.0f;
+                const float stddev = sqrtf(vm);
+                const int df = n - 1;
+                float t;
+                if (df <= 3) t = 3.182f;
+                else if (df <= 7) t = 2.365f;
+                else if (df <= 15) t = 2.131f;
+                else if (df <= 30) t = 2.042f;
+                else t = 1.96f;
+                const float half_width = t * stddev / sqrtf(fn);
+                refine = half_width > maxHalf;
+            }
+        }
+    }
+    const uint32_t q = wave_append(refine, counter);
+    if (refine) pixelsNext[q] = pix;
+}
+
+__global__ void fill_int_kernel(int* p, uint32_t n, int v) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void film_clear_kernel(rtx_film film, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    reinterpret_cast<float4*>(film.accum)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    film.count[i] = 0;
+    film.z[i] = RTX_BIG;
+    if (film.albedo) reinterpret_cast<float4*>(film.albedo)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (film.normal) reinterpret_cast<float4*>(film.normal)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+__global__ void stats_clear_kernel(PathPool pool, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    pool.statSum[i] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(0));
+    pool.statSum2[i] = make_float4(0.0f, 0.0f, 0.0f, RTX_BIG);
+}
+
+// mergeToImage + ToColor24 (RayCaster.cpp:1188-1211, 33-48); Linear2sRGB of the absent cyColor: stand-in
+// c < 0.0031308 ? 12.92 c : 1.055 c^0.41666 - 0.055
+__global__ void film_resolve_kernel(rtx_film film, uint32_t n, int srgb, float* __restrict__ linear, unsigned char* __restrict__ rgb8) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = reinterpret_cast<const float4*>(film.accum)[i];
+    float c[3] = {0.0f, 0.0f, 0.0f};
+    if (a.w > 0.0f) {
+        c[0] = a.x / a.w;
+        c[1] = a.y / a.w;
+        c[2] = a.z / a.w;
+    }
+    for (int k = 0; k < 3; ++k) {
+        if (linear) linear[3 * (size_t)i + k] = c[k];
+        float x = c[k];
+        if (srgb) x = x < 0.0031308f ? x * 12.92f : powf(x, 0.41666f) * 1.055f - 0.055f;
+        x = fmaxf(x, 0.0f);
+        x = fminf(x, 1.0f);
+        if (rgb8) rgb8[3 * (size_t)i + k] = (unsigned char)(x * 255.0f);
+    }
+}
+
+// ---- launch wrappers -------------------------------------------------------------------------------------------
+void launch_raygen(const DevCamera& cam, const PathPool& pool, const int* pixels, uint32_t nPix, int S, int sBase, int indexStride,
+                   uint32_t* queueOut, uint32_t* counters, hipStream_t stream) {
+    const uint32_t n = nPix * (uint32_t)S;
+    if (!n) return;
+    hipLaunchKernelGGL(raygen_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cam, pool, pixels, nPix, S, sBase, indexStride,
+                       queueOut, counters);
+}
+void launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm, const uint32_t* queueIn,
+                  uint32_t n, int bounce, int maxBounces, unsigned long long seed, int sBase, int S, const int* pixels,
+                  uint32_t* queueOut, uint32_t* counters, hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(shade_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sc, cam, pool, pm, queueIn, n, bounce, maxBounces,
+                       seed, sBase, S, pixels, queueOut, counters);
+}
+void launch_shadow(const DevScene& sc, const LaunchCfg& cfg, const PathPool& pool, uint32_t n, int useTransmittance) {
+    if (!n) return;
+    (void)hipMemsetAsync(cfg.workCounter, 0, sizeof(uint32_t), cfg.stream);
+    const uint32_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
+    const uint32_t grid = need < (uint32_t)cfg.gridBlocks ? need : (uint32_t)cfg.gridBlocks;
+    hipLaunchKernelGGL(shadow_kernel, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, pool, n, useTransmittance, cfg.workCounter,
+                       cfg.spill);
+}
+void launch_resolve(const PathPool& pool, const uint32_t* queueIn, uint32_t n, int nLights, int usePhotons, hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pool, queueIn, n, nLights, usePhotons);
+}
+void launch_film(const PathPool& pool, const rtx_film& film, const int* pixels, uint32_t nPix, int S, int W, int H, int filterType,
+                 float filterRadius, int resetZ, float4* samplesOut, int sBase, int sppTotal, hipStream_t stream) {
+    if (!nPix) return;
+    hipLaunchKernelGGL(film_kernel, dim3((nPix + 255) / 256), dim3(256), 0, stream, pool, film, pixels, nPix, S, W, H, filterType,
+                       filterRadius, resetZ, samplesOut, sBase, sppTotal);
+}
+void launch_adaptive(const PathPool& pool, const int* pixels, uint32_t nPix, float maxHalf, int sppMax, int* pixelsNext,
+                     uint32_t* counter, hipStream_t stream) {
+    if (!nPix) return;
+    hipLaunchKernelGGL(adaptive_kernel, dim3((nPix + 255) / 256), dim3(256), 0, stream, pool, pixels, nPix, maxHalf, sppMax,
+                       pixelsNext, counter);
+}
+void launch_fill_int(int* p, uint32_t n, int v, hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(fill_int_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, n, v);
+}
+void launch_film_clear(const rtx_film& film, uint32_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(film_clear_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, film, n);
+}
+void launch_stats_clear(const PathPool& pool, uint32_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(stats_clear_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pool, n);
+}
+void launch_film_resolve(const rtx_film& film, uint32_t n, int srgb, float* linear, unsigned char* rgb8, hipStream_t stream) {
+    hipLaunchKernelGGL(film_resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, film, n, srgb, linear, rgb8);
+}

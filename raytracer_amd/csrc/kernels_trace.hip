@@ -9,8 +9,8 @@
 template <bool COUNT>
 __global__ __launch_bounds__(TRAV_BLOCK) void extend_kernel(DevScene sc, const float4* __restrict__ rays, uint32_t n,
                                                             int hitSide, int withLights, float4* __restrict__ hits,
-                                                            uint32_t* workCounter, uint2* spill,
-                                                            unsigned long long* counters) {
+                                                            const uint32_t* __restrict__ queue, uint32_t* workCounter,
+                                                            uint2* spill, unsigned long long* counters) {
     __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -21,8 +21,9 @@ __global__ __launch_bounds__(TRAV_BLOCK) void extend_kernel(DevScene sc, const f
         if (lane == 0) base = atomicAdd(workCounter, 64u);
         base = __builtin_amdgcn_readfirstlane(base);
         if (base >= n) break;
-        const uint32_t i = base + lane;
-        if (i < n) {
+        const uint32_t qi = base + lane;
+        if (qi < n) {
+            const uint32_t i = queue ? queue[qi] : qi;   // ray queue indirection (path slots) or identity
             const float4 a = rays[2 * (size_t)i], b = rays[2 * (size_t)i + 1];
             RayT r{a.x, a.y, a.z, b.x, b.y, b.z, a.w};
             HitT h = traverse_closest<COUNT>(sc, r, hitSide, st, &nodeCount, &triCount);
@@ -39,17 +40,17 @@ __global__ __launch_bounds__(TRAV_BLOCK) void extend_kernel(DevScene sc, const f
 }
 
 void launch_extend(const DevScene& sc, const LaunchCfg& cfg, const float4* rays, uint32_t n, int hitSide, int withLights,
-                   float4* hits) {
+                   float4* hits, const uint32_t* queue) {
     if (n == 0) return;
     (void)hipMemsetAsync(cfg.workCounter, 0, sizeof(uint32_t), cfg.stream);
     const uint32_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
     const uint32_t grid = need < (uint32_t)cfg.gridBlocks ? need : (uint32_t)cfg.gridBlocks;
     if (cfg.counting)
         hipLaunchKernelGGL(extend_kernel<true>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, rays, n, hitSide,
-                           withLights, hits, cfg.workCounter, cfg.spill, cfg.counters);
+                           withLights, hits, queue, cfg.workCounter, cfg.spill, cfg.counters);
     else
         hipLaunchKernelGGL(extend_kernel<false>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, rays, n, hitSide,
-                           withLights, hits, cfg.workCounter, cfg.spill, cfg.counters);
+                           withLights, hits, queue, cfg.workCounter, cfg.spill, cfg.counters);
 }
 
 // CameraAdapter.h:7-27

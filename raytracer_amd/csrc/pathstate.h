@@ -1,0 +1,54 @@
+// Wavefront path-tracing state in HBM (structure of arrays, one entry per path slot) and the ray queues that
+// connect the kernels ray-gen -> extend -> shade -> shadow -> resolve -> film.
+//
+// A pass traces S samples of P pixels: slot = (chunk * S + s) * 64 + lane with pixel = pixels[chunk * 64 + lane],
+// so the 64 lanes of a wave hold the same sample index of 64 neighbouring pixels (a 16x4 block of one bucket).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "layout.h"
+
+#define PF_LAST_DELTA 1u
+#define PF_INSIDE_MEDIUM 2u
+#define PF_HAS_PREV 4u
+
+struct DevPhotonMap {
+    const float4* pos;      // xyz, w unused          (sorted by cell)
+    const float4* dir;      // xyz
+    const float4* power;    // rgb, already scaled
+    const uint32_t* cellStart;  // gx*gy*gz + 1
+    float gmin[3];
+    float cell;
+    int gx, gy, gz;
+    int n;
+    float radius;
+    int maxPhotons;         // 30 / 50 / 100 (RayCaster.cpp:149-151)
+};
+
+struct PathPool {
+    uint32_t capacity;      // slots
+    // per slot
+    float4* rays;           // 2 per slot: {o.xyz, tmax}, {d.xyz, 0}
+    float4* hits;           // {t, u, v, bits(slot of triangle / light code)}
+    float4* L;              // radiance rgb, w = primaryDist
+    float4* beta;           // throughput rgb, w = lastPdf
+    float4* medium;         // absorption rgb, w = bits(flags)
+    float4* prevP;          // previous hit point (SamplerInfo of the previous bounce), xyz
+    float4* pendBeta;       // throughput at the NEE of the current bounce
+    float4* nee;            // [light][slot]: contribution rgb, w = transmittance (-1: no shadow ray)
+    float4* caustic;        // kd/pi * irradiance * boost, w = valid      (only with photons)
+    float4* albedo;         // first-hit albedo, w = hit flag
+    float4* normal;         // first-hit geometric normal
+    float2* samplePos;      // film position of the sample
+    // queues
+    uint32_t* queueA;
+    uint32_t* queueB;
+    float4* shadowQ;        // 2 per entry: {offset origin xyz, maxDist}, {unit dir xyz, bits(slot*8+light)}
+    uint32_t* counters;     // [0] next-queue count, [1] shadow-queue count, [2..] scratch
+    // per pixel (full frame)
+    int* pixels;            // pixel list of the current round (padded to 64 with -1)
+    int* pixelsNext;
+    float4* statSum;        // sum rgb, w = bits(n)
+    float4* statSum2;       // sum of squares rgb, w = running bestZ
+    unsigned long long* rayCounters;  // [0] shadow hops
+};

@@ -1,18 +1,408 @@
-// placeholder (replaced by the path-tracing host orchestration)
+// C ABI (include/rtx.h): CastRays on the GPU — host orchestration of the wavefront path tracer.
+// Replaces RayCaster::CastRays / RenderBucket (reference RayTracer/RayCaster.cpp:697-1023, 1146-1314): buckets of
+// this rank -> pixel list -> passes of S samples per pixel through ray-gen / extend / shade / shadow / resolve ->
+// film accumulation -> confidence-interval test -> refinement rounds.
 #include "rtx_internal.h"
-extern "C" {
-void rtx_scene_release_pool(rtx_scene* s) { (void)s; }
-#define NOTYET return rtx_fail(RTX_ERR_INVALID, "not implemented yet")
-int rtx_film_clear(const rtx_film*, int, int, void*) { NOTYET; }
-int rtx_render_accumulate(rtx_scene*, const rtx_camera*, const rtx_render_params*, rtx_photons*, const rtx_film*, rtx_stats*) { NOTYET; }
-int rtx_film_resolve(const rtx_film*, const rtx_camera*, float*, unsigned char*, float*, int*, float*, float*) { NOTYET; }
-int rtx_render(rtx_scene*, const rtx_camera*, const rtx_render_params*, rtx_photons*, float*, unsigned char*, float*, int*, rtx_stats*) { NOTYET; }
-int rtx_render_samples(rtx_scene*, const rtx_camera*, const rtx_render_params*, rtx_photons*, float*, rtx_stats*) { NOTYET; }
-int rtx_photon_build(rtx_scene*, const rtx_photon_params*, rtx_photons**, rtx_stats*) { NOTYET; }
-void rtx_photons_destroy(rtx_photons*) {}
-int rtx_photon_info(const rtx_photons*, uint64_t*, float*) { NOTYET; }
-int64_t rtx_photon_download(const rtx_photons*, int, rtx_photon*, size_t) { NOTYET; }
-int rtx_photon_set(rtx_photons*, int, const void*, size_t, int) { NOTYET; }
-void* rtx_photon_device_ptr(const rtx_photons*, int) { return nullptr; }
-int rtx_photon_estimate(rtx_photons*, int, const float*, const float*, size_t, float*) { NOTYET; }
+#include "pathstate.h"
+#include "photon.h"
+#include <algorithm>
+#include <cstring>
+
+struct PathPoolHost {
+    PathPool dev{};
+    std::vector<void*> allocs;
+    uint32_t capacity = 0;
+    int nLights = 0;
+    size_t framePixels = 0;
+    bool hasCaustic = false;
+    std::vector<hipEvent_t> events;
+    size_t bytes = 0;
+    void release() {
+        for (void* p : allocs) (void)hipFree(p);
+        allocs.clear();
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        events.clear();
+        capacity = 0;
+        framePixels = 0;
+        bytes = 0;
+    }
+};
+
+extern "C" void rtx_scene_release_pool(rtx_scene* s) {
+    if (s && s->pool) {
+        reinterpret_cast<PathPoolHost*>(s->pool)->release();
+        delete reinterpret_cast<PathPoolHost*>(s->pool);
+        s->pool = nullptr;
+    }
 }
+
+template <class T>
+static int pool_alloc(PathPoolHost* ph, T** out, size_t count) {
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return rtx_fail(RTX_ERR_HIP, std::string("path pool hipMalloc: ") + hipGetErrorString(e));
+    ph->allocs.push_back(p);
+    ph->bytes += bytes;
+    *out = (T*)p;
+    return RTX_OK;
+}
+
+static int ensure_pool(rtx_scene* s, uint32_t slots, size_t framePixels, size_t listPixels, bool caustic) {
+    PathPoolHost* ph = reinterpret_cast<PathPoolHost*>(s->pool);
+    const int nL = std::max(1, s->dev.n_lights);
+    if (ph && ph->capacity >= slots && ph->framePixels >= std::max(framePixels, listPixels) && ph->nLights == nL &&
+        (ph->hasCaustic || !caustic))
+        return RTX_OK;
+    rtx_scene_release_pool(s);
+    ph = new PathPoolHost();
+    s->pool = reinterpret_cast<PathPool*>(ph);
+    ph->capacity = slots;
+    ph->nLights = nL;
+    ph->framePixels = std::max(framePixels, listPixels);
+    ph->hasCaustic = caustic;
+    PathPool& d = ph->dev;
+    d.capacity = slots;
+    int rc;
+#define PA(field, count) \
+    if ((rc = pool_alloc(ph, &d.field, (count))) != RTX_OK) return rc;
+    PA(rays, 2 * (size_t)slots);
+    PA(hits, slots);
+    PA(L, slots);
+    PA(beta, slots);
+    PA(medium, slots);
+    PA(prevP, slots);
+    PA(pendBeta, slots);
+    PA(nee, (size_t)nL * slots);
+    PA(caustic, caustic ? slots : 1);
+    PA(albedo, slots);
+    PA(normal, slots);
+    PA(samplePos, slots);
+    PA(queueA, slots);
+    PA(queueB, slots);
+    PA(shadowQ, 2 * (size_t)nL * slots);
+    PA(counters, 64);
+    PA(pixels, ph->framePixels + 64);
+    PA(pixelsNext, ph->framePixels + 64);
+    PA(statSum, ph->framePixels);
+    PA(statSum2, ph->framePixels);
+    PA(rayCounters, 8);
+#undef PA
+    return RTX_OK;
+}
+
+// Pixel list of the buckets owned by (rank, world): RayCaster.cpp:1152-1158 builds 16x16 buckets row-major; bucket b
+// belongs to rank b % world. Inside a bucket pixels are emitted as 16x4 blocks (one wave each).
+static void build_pixel_list(int W, int H, int bs, int rank, int world, std::vector<int>& list, size_t& nValid) {
+    list.clear();
+    nValid = 0;
+    int b = 0;
+    for (int y = 0; y < H; y += bs)
+        for (int x = 0; x < W; x += bs, ++b) {
+            if (b % world != rank) continue;
+            const int x1 = std::min(x + bs, W), y1 = std::min(y + bs, H);
+            // blocks of up to 16 columns x 4 rows -> exactly 64 entries each (pad with -1)
+            for (int by = y; by < y1; by += 4)
+                for (int bx = x; bx < x1; bx += 16) {
+                    for (int r = 0; r < 4; ++r)
+                        for (int c = 0; c < 16; ++c) {
+                            const int px = bx + c, py = by + r;
+                            if (px < x1 && py < y1) {
+                                list.push_back(py * W + px);
+                                ++nValid;
+                            } else
+                                list.push_back(-1);
+                        }
+                }
+        }
+}
+
+struct PassTimers {
+    PathPoolHost* ph;
+    size_t used = 0;
+    std::vector<std::pair<int, std::pair<size_t, size_t>>> spans;   // kind, (start,stop) event index
+    double ms[3] = {0, 0, 0};
+    hipEvent_t get() {
+        if (used == ph->events.size()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            ph->events.push_back(e);
+        }
+        return ph->events[used++];
+    }
+    void begin(int kind, hipStream_t st) {
+        hipEvent_t e = get();
+        (void)hipEventRecord(e, st);
+        spans.push_back({kind, {used - 1, 0}});
+    }
+    void end(hipStream_t st) {
+        hipEvent_t e = get();
+        (void)hipEventRecord(e, st);
+        spans.back().second.second = used - 1;
+    }
+    void flush() {   // caller has synchronised the stream
+        for (auto& s : spans) {
+            float t = 0.0f;
+            if (hipEventElapsedTime(&t, ph->events[s.second.first], ph->events[s.second.second]) == hipSuccess) ms[s.first] += t;
+        }
+        spans.clear();
+        used = 0;
+    }
+};
+
+static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_params* rp, rtx_photons* photons, const rtx_film* film,
+                       rtx_stats* stats, float4* samplesOut) {
+    if (!s || !cam || !rp || !film) return rtx_fail(RTX_ERR_INVALID, "NULL argument");
+    if (!film->accum || !film->count || !film->z) return rtx_fail(RTX_ERR_INVALID, "film.accum/count/z must be device buffers");
+    if (rp->spp_min < 1 || rp->spp_max < rp->spp_min) return rtx_fail(RTX_ERR_INVALID, "need 1 <= spp_min <= spp_max");
+    if (rp->max_bounces < 1) return rtx_fail(RTX_ERR_INVALID, "max_bounces must be >= 1");
+    const int world = rp->world > 0 ? rp->world : 1;
+    if (rp->rank < 0 || rp->rank >= world) return rtx_fail(RTX_ERR_INVALID, "rank out of range");
+    DevCamera dc;
+    int rc;
+    if ((rc = make_dev_camera(cam, dc)) != RTX_OK) return rc;
+    const int W = dc.W, H = dc.H;
+    const int stride = rp->index_stride > 0 ? rp->index_stride : 1024;
+    if ((long long)W * H * stride + rp->spp_max + 1 > 2147483647LL)
+        return rtx_fail(RTX_ERR_TOO_LARGE, "sampleIndex = (y*W+x)*index_stride+s+1 overflows int (RayCaster.cpp:784)");
+    if (rp->spp_max > stride) return rtx_fail(RTX_ERR_INVALID, "spp_max exceeds index_stride");
+    const int bs = rp->tile_size > 0 ? rp->tile_size : 16;
+
+    std::vector<int> list;
+    size_t nValid = 0;
+    build_pixel_list(W, H, bs, rp->rank, world, list, nValid);
+    uint32_t nPix = (uint32_t)list.size();
+
+    DevPhotonMap pm;
+    std::memset(&pm, 0, sizeof(pm));
+    const bool usePhotons = photons && rp->use_photons;
+    if (usePhotons) photon_device_map(photons, 1, pm);
+
+    // path pool sizing: S samples per pixel per pass
+    int S = rp->samples_per_pass;
+    if (S <= 0) {
+        const size_t target = 16u << 20;   // ~16M slots (about 5 GB of path state at 3 lights)
+        S = (int)std::max<size_t>(1, std::min<size_t>((size_t)rp->spp_min, target / std::max<uint32_t>(nPix, 1)));
+    }
+    S = std::min(S, rp->spp_min);
+    if ((size_t)nPix * S > 0x7FFFFFFFull / 8) return rtx_fail(RTX_ERR_TOO_LARGE, "path pool too large; lower samples_per_pass");
+    if ((rc = ensure_pool(s, nPix * (uint32_t)S, (size_t)W * H, nPix, usePhotons)) != RTX_OK) return rc;
+    PathPoolHost* ph = reinterpret_cast<PathPoolHost*>(s->pool);
+    PathPool& pool = ph->dev;
+    hipStream_t st = s->cfg.stream;
+
+    rtx_stats out;
+    std::memset(&out, 0, sizeof(out));
+    hipEvent_t evTotal0 = nullptr, evTotal1 = nullptr;
+    RTX_HIP(hipEventCreate(&evTotal0));
+    RTX_HIP(hipEventCreate(&evTotal1));
+    RTX_HIP(hipEventRecord(evTotal0, st));
+
+    if (nPix) RTX_HIP(hipMemcpyAsync(pool.pixels, list.data(), (size_t)nPix * sizeof(int), hipMemcpyHostToDevice, st));
+    launch_stats_clear(pool, (uint32_t)((size_t)W * H), st);
+    RTX_HIP(hipMemsetAsync(pool.rayCounters, 0, 8 * sizeof(unsigned long long), st));
+    if (s->cfg.counting) RTX_HIP(hipMemsetAsync(s->cfg.counters, 0, 3 * sizeof(unsigned long long), st));
+
+    PassTimers tm{ph};
+    int* curPixels = pool.pixels;
+    int* nextPixels = pool.pixelsNext;
+    size_t curValid = nValid;
+    int roundBase = 0;
+    for (int round = 0; nPix > 0 && curValid > 0; ++round) {
+        const int target = std::min(rp->spp_min, rp->spp_max - roundBase);
+        if (target <= 0) break;
+        for (int done = 0; done < target;) {
+            const int Sp = std::min(S, target - done);
+            const int sBase = roundBase + done;
+            // ---- one wavefront pass ----
+            RTX_HIP(hipMemsetAsync(pool.counters, 0, 8 * sizeof(uint32_t), st));
+            uint32_t* qin = pool.queueA;
+            uint32_t* qout = pool.queueB;
+            launch_raygen(dc, pool, curPixels, nPix, Sp, sBase, stride, qin, pool.counters, st);
+            uint32_t n = (uint32_t)(curValid * (size_t)Sp);
+            out.paths += n;
+            for (int bounce = 0; bounce < rp->max_bounces && n > 0; ++bounce) {
+                if (bounce == 0) out.rays_primary += n;
+                else out.rays_bounce += n;
+                tm.begin(0, st);
+                launch_extend(s->dev, s->cfg, pool.rays, n, RTX_HIT_FRONT_AND_BACK, 1, pool.hits, qin);
+                tm.end(st);
+                out.extend_launches++;
+                RTX_HIP(hipMemsetAsync(pool.counters, 0, 2 * sizeof(uint32_t), st));
+                tm.begin(2, st);
+                launch_shade(s->dev, dc, pool, pm, qin, n, bounce, rp->max_bounces, rp->seed, sBase, Sp, curPixels, qout,
+                             pool.counters, st);
+                tm.end(st);
+                uint32_t cnt[2] = {0, 0};
+                RTX_HIP(hipMemcpyAsync(cnt, pool.counters, sizeof(cnt), hipMemcpyDeviceToHost, st));
+                RTX_HIP(hipStreamSynchronize(st));
+                if (cnt[1]) {
+                    tm.begin(1, st);
+                    launch_shadow(s->dev, s->cfg, pool, cnt[1], bounce <= 8 ? 1 : 0);   // useTransmittance (RayCaster.cpp:454)
+                    tm.end(st);
+                }
+                launch_resolve(pool, qin, n, s->dev.n_lights, usePhotons ? 1 : 0, st);
+                std::swap(qin, qout);
+                n = cnt[0];
+                if (tm.spans.size() > 2048) {
+                    RTX_HIP(hipStreamSynchronize(st));
+                    tm.flush();
+                }
+            }
+            launch_film(pool, *film, curPixels, nPix, Sp, W, H, rp->filter_type, rp->filter_radius, (round == 1 && done == 0) ? 1 : 0,
+                        samplesOut, sBase, rp->spp_max, st);
+            done += Sp;
+        }
+        roundBase += target;
+        if (rp->spp_max <= rp->spp_min || roundBase >= rp->spp_max) break;
+        // ---- confidence-interval test -> next pixel list ----
+        launch_fill_int(nextPixels, nPix, -1, st);
+        RTX_HIP(hipMemsetAsync(pool.counters + 8, 0, sizeof(uint32_t), st));
+        launch_adaptive(pool, curPixels, nPix, rp->ci_halfwidth, rp->spp_max, nextPixels, pool.counters + 8, st);
+        uint32_t cnt = 0;
+        RTX_HIP(hipMemcpyAsync(&cnt, pool.counters + 8, sizeof(cnt), hipMemcpyDeviceToHost, st));
+        RTX_HIP(hipStreamSynchronize(st));
+        curValid = cnt;
+        nPix = (cnt + 63u) & ~63u;
+        std::swap(curPixels, nextPixels);
+    }
+    RTX_HIP(hipEventRecord(evTotal1, st));
+    RTX_HIP(hipStreamSynchronize(st));
+    RTX_HIP(hipGetLastError());
+    tm.flush();
+    float total = 0.0f;
+    (void)hipEventElapsedTime(&total, evTotal0, evTotal1);
+    (void)hipEventDestroy(evTotal0);
+    (void)hipEventDestroy(evTotal1);
+    unsigned long long hops = 0;
+    RTX_HIP(hipMemcpy(&hops, pool.rayCounters, sizeof(hops), hipMemcpyDeviceToHost));
+    out.rays_shadow = hops;
+    out.extend_ms = tm.ms[0];
+    out.shadow_ms = tm.ms[1];
+    out.shade_ms = tm.ms[2];
+    out.total_ms = total;
+    if (s->cfg.counting) {
+        unsigned long long c[3];
+        RTX_HIP(hipMemcpy(c, s->cfg.counters, sizeof(c), hipMemcpyDeviceToHost));
+        out.nodes_visited = c[0];
+        out.tris_tested = c[1];
+    }
+    if (stats) *stats = out;
+    return RTX_OK;
+}
+
+extern "C" {
+
+int rtx_film_clear(const rtx_film* film, int width, int height, void* stream) {
+    if (!film || !film->accum || !film->count || !film->z || width <= 0 || height <= 0) return rtx_fail(RTX_ERR_INVALID, "bad film");
+    if (rtx_device_count() <= 0) return rtx_fail(RTX_ERR_NO_DEVICE, "no HIP device present");
+    launch_film_clear(*film, (uint32_t)((size_t)width * height), (hipStream_t)stream);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+int rtx_render_accumulate(rtx_scene* s, const rtx_camera* cam, const rtx_render_params* rp, rtx_photons* photons,
+                          const rtx_film* film, rtx_stats* stats) {
+    return render_impl(s, cam, rp, photons, film, stats, nullptr);
+}
+
+int rtx_film_resolve(const rtx_film* film, const rtx_camera* cam, float* linear_rgb, unsigned char* rgb8, float* z, int* samples,
+                     float* albedo, float* normal) {
+    if (!film || !cam || !film->accum) return rtx_fail(RTX_ERR_INVALID, "bad film");
+    if (rtx_device_count() <= 0) return rtx_fail(RTX_ERR_NO_DEVICE, "no HIP device present");
+    const size_t n = (size_t)cam->width * cam->height;
+    float* dLin = nullptr;
+    unsigned char* d8 = nullptr;
+    RTX_HIP(hipMalloc((void**)&dLin, n * 3 * sizeof(float)));
+    if (hipMalloc((void**)&d8, n * 3) != hipSuccess) {
+        (void)hipFree(dLin);
+        return rtx_fail(RTX_ERR_HIP, "hipMalloc failed");
+    }
+    launch_film_resolve(*film, (uint32_t)n, cam->srgb, dLin, d8, nullptr);
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess && linear_rgb) e = hipMemcpy(linear_rgb, dLin, n * 3 * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && rgb8) e = hipMemcpy(rgb8, d8, n * 3, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && z) e = hipMemcpy(z, film->z, n * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && samples) e = hipMemcpy(samples, film->count, n * sizeof(int), hipMemcpyDeviceToHost);
+    std::vector<float> tmp;
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        float* dst = k ? normal : albedo;
+        const float* src = k ? film->normal : film->albedo;
+        if (!dst) continue;
+        if (!src) {
+            std::memset(dst, 0, n * 3 * sizeof(float));
+            continue;
+        }
+        tmp.resize(n * 4);
+        e = hipMemcpy(tmp.data(), src, n * 4 * sizeof(float), hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < n; ++i) {
+            dst[3 * i] = tmp[4 * i];
+            dst[3 * i + 1] = tmp[4 * i + 1];
+            dst[3 * i + 2] = tmp[4 * i + 2];
+        }
+    }
+    (void)hipFree(dLin);
+    (void)hipFree(d8);
+    if (e != hipSuccess) return rtx_fail(RTX_ERR_HIP, std::string("film resolve: ") + hipGetErrorString(e));
+    return RTX_OK;
+}
+
+static int alloc_film(size_t n, rtx_film& f, std::vector<void*>& owned) {
+    void* p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t sz[5] = {n * 16, n * 4, n * 4, n * 16, n * 16};
+    for (int k = 0; k < 5; ++k) {
+        if (hipMalloc(&p[k], sz[k]) != hipSuccess) {
+            for (void* q : owned) (void)hipFree(q);
+            owned.clear();
+            return rtx_fail(RTX_ERR_HIP, "film allocation failed");
+        }
+        owned.push_back(p[k]);
+    }
+    f.accum = (float*)p[0];
+    f.count = (int*)p[1];
+    f.z = (float*)p[2];
+    f.albedo = (float*)p[3];
+    f.normal = (float*)p[4];
+    return RTX_OK;
+}
+
+int rtx_render(rtx_scene* s, const rtx_camera* cam, const rtx_render_params* rp, rtx_photons* photons, float* linear_rgb,
+               unsigned char* rgb8, float* z, int* samples, rtx_stats* stats) {
+    if (!s || !cam) return rtx_fail(RTX_ERR_INVALID, "NULL argument");
+    const size_t n = (size_t)cam->width * cam->height;
+    rtx_film f;
+    std::vector<void*> owned;
+    int rc = alloc_film(n, f, owned);
+    if (rc != RTX_OK) return rc;
+    rc = rtx_film_clear(&f, cam->width, cam->height, nullptr);
+    if (rc == RTX_OK) rc = render_impl(s, cam, rp, photons, &f, stats, nullptr);
+    if (rc == RTX_OK) rc = rtx_film_resolve(&f, cam, linear_rgb, rgb8, z, samples, nullptr, nullptr);
+    for (void* q : owned) (void)hipFree(q);
+    return rc;
+}
+
+int rtx_render_samples(rtx_scene* s, const rtx_camera* cam, const rtx_render_params* rp, rtx_photons* photons, float* out,
+                       rtx_stats* stats) {
+    if (!s || !cam || !rp || !out) return rtx_fail(RTX_ERR_INVALID, "NULL argument");
+    if (rp->spp_max != rp->spp_min) return rtx_fail(RTX_ERR_INVALID, "rtx_render_samples needs a fixed sample count");
+    const size_t n = (size_t)cam->width * cam->height;
+    rtx_film f;
+    std::vector<void*> owned;
+    int rc = alloc_film(n, f, owned);
+    if (rc != RTX_OK) return rc;
+    float4* dS = nullptr;
+    const size_t bytes = n * (size_t)rp->spp_min * sizeof(float4);
+    if (hipMalloc((void**)&dS, bytes) != hipSuccess) {
+        for (void* q : owned) (void)hipFree(q);
+        return rtx_fail(RTX_ERR_HIP, "sample buffer allocation failed");
+    }
+    (void)hipMemset(dS, 0, bytes);
+    rc = rtx_film_clear(&f, cam->width, cam->height, nullptr);
+    if (rc == RTX_OK) rc = render_impl(s, cam, rp, photons, &f, stats, dS);
+    if (rc == RTX_OK && hipMemcpy(out, dS, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = rtx_fail(RTX_ERR_HIP, "copy failed");
+    (void)hipFree(dS);
+    for (void* q : owned) (void)hipFree(q);
+    return rc;
+}
+
+}  // extern "C"

@@ -24,12 +24,10 @@ __device__ __forceinline__ void triangle_gn(const DevScene& sc, const RayT& r, i
     obj = (int)(sc.attrs[slot].obj_mtl & 0xFFFFu);
 }
 
+// o = OffsetPoint(origin, normal, dir), d = SafeNormalize(dir) already applied (RayCaster.cpp:199)
 template <bool COUNT>
-__device__ __forceinline__ float visible_chain(const DevScene& sc, f3 origin, f3 normal, f3 dirIn, float maxDist,
-                                               bool useTransmittance, TravStack st, uint32_t* hops, uint32_t* nodeCount,
-                                               uint32_t* triCount) {
-    const f3 d = safe_normalize3(dirIn);
-    f3 o = offset_point(origin, normal, dirIn);
+__device__ __forceinline__ float visible_chain_from(const DevScene& sc, f3 o, f3 d, float maxDist, bool useTransmittance,
+                                                    TravStack st, uint32_t* hops, uint32_t* nodeCount, uint32_t* triCount) {
     const int kMaxHops = useTransmittance ? 8 : 1;
     float visibility = 1.0f;
     for (int hop = 0; hop < kMaxHops; ++hop) {
@@ -68,4 +66,12 @@ __device__ __forceinline__ float visible_chain(const DevScene& sc, f3 origin, f3
         if (maxDist <= 1e-4f) return visibility;
     }
     return useTransmittance ? 0.0f : visibility;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ float visible_chain(const DevScene& sc, f3 origin, f3 normal, f3 dirIn, float maxDist,
+                                               bool useTransmittance, TravStack st, uint32_t* hops, uint32_t* nodeCount,
+                                               uint32_t* triCount) {
+    return visible_chain_from<COUNT>(sc, offset_point(origin, normal, dirIn), safe_normalize3(dirIn), maxDist, useTransmittance,
+                                     st, hops, nodeCount, triCount);
 }

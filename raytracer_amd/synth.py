@@ -180,7 +180,7 @@ def wavy_disc(r, amp, nu, nv):
     V2 = V.copy()
     V2[:, 1] -= 0.004
     return (np.concatenate([V, V2]), np.concatenate([Nn, -Nn]), np.concatenate([UV, UV]),
-            np.concatenate([F[:, ::-1], F + len(V)]))
+            np.concatenate([F, F[:, ::-1] + len(V)]))
 
 
 def bowl(r, nu, nv, thickness=0.03):
@@ -211,7 +211,7 @@ def bowl(r, nu, nv, thickness=0.03):
     V = np.concatenate([Vo, Vi, Vr])
     N = np.concatenate([No_, Ni_, Nr])
     UV = np.concatenate([UVo, UVi, UVr])
-    F = np.concatenate([Fo, Fi[:, ::-1] + len(Vo), Fr[:, ::-1] + len(Vo) + len(Vi)])
+    F = np.concatenate([Fo[:, ::-1], Fi + len(Vo), Fr + len(Vo) + len(Vi)])
     return V.astype(np.float32), N.astype(np.float32), UV.astype(np.float32), F.astype(np.int32)
 
 
