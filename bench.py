@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 import raytracer_amd as ra  # noqa: E402
 from raytracer_amd import synth, _ffi  # noqa: E402
 from raytracer_amd.scene import render_params  # noqa: E402
+from raytracer_amd.distributed import reduce_film  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
@@ -43,7 +44,7 @@ def parse():
     ap.add_argument("--max-bounces", type=int, default=64)
     ap.add_argument("--samples-per-pass", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=8)
+    ap.add_argument("--cpu-spp", type=int, default=96)
     return ap.parse_args()
 
 
@@ -81,10 +82,7 @@ def main():
     def step():
         ra.film_clear(film, W, H)
         st = scene.render_accumulate(cam, rp, film)
-        if world > 1:
-            dist.reduce(tens["accum"], 0, op=dist.ReduceOp.SUM)
-            dist.reduce(tens["count"], 0, op=dist.ReduceOp.SUM)
-            dist.reduce(tens["z"], 0, op=dist.ReduceOp.MIN)
+        reduce_film(tens["accum"], tens["count"], tens["z"], dst=0)   # RCCL over xGMI; no-op at world == 1
         return st
 
     def sync():

@@ -307,6 +307,14 @@ int rtx_set_counters(rtx_scene* scene, int enabled);
  * the algorithmic bytes per ray of SURVEY.md §8(d): 48 + nodes*64 + tris*48. */
 int rtx_get_counters(rtx_scene* scene, uint64_t out[3]);
 
+/* Host-only checks (no device needed; used by the CPU test-suite). No counterpart in the reference.
+ * rtx_debug_validate_bvh: flattens desc and verifies the BVH (every triangle in exactly one leaf, quantised boxes
+ * conservative); out[0]=triangles, [1]=nodes, [2]=depth.
+ * rtx_debug_pixel_list: the padded pixel list (64-pixel wave blocks, -1 = padding) of the buckets that
+ * RayCaster.cpp:1152-1158 would build and that belong to `rank` of `world`; returns its length. */
+int rtx_debug_validate_bvh(const rtx_scene_desc* desc, uint64_t out[3]);
+int64_t rtx_debug_pixel_list(int width, int height, int tile, int rank, int world, int* out, size_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

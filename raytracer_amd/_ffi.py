@@ -145,6 +145,8 @@ SYMBOLS = [
     ("rtx_photon_estimate", C.c_int, [_vp, C.c_int, _vp, _vp, C.c_size_t, _vp]),
     ("rtx_set_counters", C.c_int, [_vp, C.c_int]),
     ("rtx_get_counters", C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    ("rtx_debug_validate_bvh", C.c_int, [C.POINTER(SceneDesc), C.POINTER(C.c_uint64)]),
+    ("rtx_debug_pixel_list", C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t]),
 ]
 
 _lib = None

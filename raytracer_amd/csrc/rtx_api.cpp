@@ -271,6 +271,22 @@ void rtx_scene_destroy(rtx_scene* s) {
     delete s;
 }
 
+// Host-only checks of the flattening logic (no device needed): builds the BVH for desc and validates it.
+// out[0]=triangles, [1]=nodes, [2]=depth. Returns RTX_OK or RTX_ERR_INVALID with the reason in rtx_last_error().
+int rtx_debug_validate_bvh(const rtx_scene_desc* desc, uint64_t out[3]) {
+    HostScene hs;
+    std::string err;
+    if (!build_host_scene(desc, hs, err)) return rtx_fail(RTX_ERR_INVALID, err);
+    err = validate_host_scene(hs);
+    if (!err.empty()) return rtx_fail(RTX_ERR_INVALID, err);
+    if (out) {
+        out[0] = hs.tris.size();
+        out[1] = hs.nodes.size();
+        out[2] = (uint64_t)hs.depth;
+    }
+    return RTX_OK;
+}
+
 int rtx_scene_info(const rtx_scene* s, uint64_t counts[6], float bounds[6]) {
     if (!s) return rtx_fail(RTX_ERR_INVALID, "scene is NULL");
     if (counts) {

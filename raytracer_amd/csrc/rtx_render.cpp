@@ -117,6 +117,16 @@ static void build_pixel_list(int W, int H, int bs, int rank, int world, std::vec
         }
 }
 
+// Host-only view of the tile sharding (no device needed): the padded pixel list of (rank, world).
+extern "C" int64_t rtx_debug_pixel_list(int W, int H, int tile, int rank, int world, int* out, size_t capacity) {
+    if (W <= 0 || H <= 0 || world < 1 || rank < 0 || rank >= world) return rtx_fail(RTX_ERR_INVALID, "bad argument");
+    std::vector<int> list;
+    size_t nValid = 0;
+    build_pixel_list(W, H, tile > 0 ? tile : 16, rank, world, list, nValid);
+    if (out) std::memcpy(out, list.data(), std::min(capacity, list.size()) * sizeof(int));
+    return (int64_t)list.size();
+}
+
 struct PassTimers {
     PathPoolHost* ph;
     size_t used = 0;

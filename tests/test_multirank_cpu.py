@@ -1,0 +1,65 @@
+"""world_size-2 test of the multi-rank path on CPU (gloo): each rank renders the buckets it owns into a full-frame
+film, the films are reduced with raytracer_amd.distributed.reduce_film (the code bench.py uses over RCCL), and the
+result equals the single-rank render. The oracle stands in for the per-rank renderer; the reduction protocol and the
+bucket ownership rule are the parts under test."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from raytracer_amd import synth
+from raytracer_amd.distributed import reduce_film, photon_split
+from raytracer_amd.scene import render_params
+from tests.oracle_ffi import OracleScene, OraclePhotons
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sd = synth.build_scene(0.002)
+    cam = synth.cerealbar_camera(48, 27)
+    osc = OracleScene(sd)
+    r = osc.render(cam, render_params(spp_min=4, max_bounces=8, rank=rank, world=world))
+    n = 48 * 27
+    accum = torch.from_numpy(r["accum"].reshape(n, 4).copy())
+    count = torch.from_numpy(r["samples"].reshape(n).copy())
+    z = torch.from_numpy(r["z"].reshape(n).copy())
+    own = int(count.sum())
+    reduce_film(accum, count, z, dst=0)
+    # photon ids are split by stride; counts add up
+    ph = OraclePhotons(osc, 20000, finalize=False, **photon_split(rank, world))
+    cnt = torch.tensor([ph.info()["n_global"], ph.info()["n_caustic"], own], dtype=torch.int64)
+    dist.all_reduce(cnt)
+    if rank == 0:
+        np.savez(out_path, accum=accum.numpy(), count=count.numpy(), z=z.numpy(), cnt=cnt.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_film_reduce_equals_single_rank(tmp_path):
+    out = str(tmp_path / "r.npz")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    sd = synth.build_scene(0.002)
+    cam = synth.cerealbar_camera(48, 27)
+    osc = OracleScene(sd)
+    ref = osc.render(cam, render_params(spp_min=4, max_bounces=8))
+    n = 48 * 27
+    assert np.array_equal(got["count"], ref["samples"].reshape(n))          # every pixel sampled by exactly one rank
+    assert got["cnt"][2] == n * 4
+    assert np.array_equal(got["z"], ref["z"].reshape(n))
+    assert np.allclose(got["accum"], ref["accum"].reshape(n, 4), rtol=1e-5, atol=1e-6)   # float sum order only
+    ph = OraclePhotons(osc, 20000, finalize=False)
+    assert got["cnt"][0] == ph.info()["n_global"] and got["cnt"][1] == ph.info()["n_caustic"]
