@@ -266,6 +266,11 @@ int rtx_render_accumulate(rtx_scene* scene, const rtx_camera* cam, const rtx_ren
 int rtx_film_resolve(const rtx_film* film, const rtx_camera* cam, float* linear_rgb, unsigned char* rgb8,
                      float* z, int* samples, float* albedo, float* normal);
 
+/* Replaces: RayCaster::Stop (RayCaster.cpp:1316-1318): asks an in-flight rtx_render* call on this scene (running in
+ * another thread) to stop after the current bounce; that call returns RTX_OK with the samples accumulated so far.
+ * The flag is cleared when the next render call starts. Async-safe. */
+int rtx_cancel(rtx_scene* scene);
+
 /* Convenience single-GPU CastRays: clear + accumulate + resolve. */
 int rtx_render(rtx_scene* scene, const rtx_camera* cam, const rtx_render_params* params, rtx_photons* photons,
                float* linear_rgb, unsigned char* rgb8, float* z, int* samples, rtx_stats* stats);

@@ -133,6 +133,7 @@ SYMBOLS = [
     ("rtx_render_accumulate", C.c_int, [_vp, C.POINTER(Camera), C.POINTER(RenderParams), _vp, C.POINTER(Film),
                                         C.POINTER(Stats)]),
     ("rtx_film_resolve", C.c_int, [C.POINTER(Film), C.POINTER(Camera), _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("rtx_cancel", C.c_int, [_vp]),
     ("rtx_render", C.c_int, [_vp, C.POINTER(Camera), C.POINTER(RenderParams), _vp, _vp, _vp, _vp, _vp,
                              C.POINTER(Stats)]),
     ("rtx_render_samples", C.c_int, [_vp, C.POINTER(Camera), C.POINTER(RenderParams), _vp, _vp, C.POINTER(Stats)]),

@@ -1,6 +1,7 @@
 // Internal host-side state behind the opaque C-ABI handles.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <string>
 #include <vector>
 #include "bvh_build.h"
@@ -31,6 +32,7 @@ struct rtx_scene {
     int depth = 0;
     LaunchCfg cfg{};
     int numCUs = 0;
+    std::atomic<int> cancel{0};   // rtx_cancel
     // reusable scratch for the host-array entry points
     DevBuf rays, hits, full, aux, aux2;
     // path-tracing pool (kernels_path.hip)

@@ -191,11 +191,19 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     // path pool sizing: S samples per pixel per pass
     int S = rp->samples_per_pass;
     if (S <= 0) {
-        const size_t target = 16u << 20;   // ~16M slots (about 5 GB of path state at 3 lights)
+        // Size the path pool for the 288 GB of HBM: the deeper bounces of a pass hold few paths (Russian roulette),
+        // so fewer, larger passes amortise that tail. Use up to 40 % of the free memory, at most 96 GB.
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = (size_t)8 << 30;
+        const size_t perSlot = 192 + 48 * (size_t)std::max(1, s->dev.n_lights);
+        const size_t budget = std::min<size_t>((size_t)(0.4 * (double)freeB), (size_t)96 << 30);
+        const size_t target = std::max<size_t>(budget / perSlot, 1u << 20);
         S = (int)std::max<size_t>(1, std::min<size_t>((size_t)rp->spp_min, target / std::max<uint32_t>(nPix, 1)));
     }
     S = std::min(S, rp->spp_min);
-    if ((size_t)nPix * S > 0x7FFFFFFFull / 8) return rtx_fail(RTX_ERR_TOO_LARGE, "path pool too large; lower samples_per_pass");
+    // slot * 8 + light must fit 32 bits (shadow queue entries)
+    while (S > 1 && (size_t)nPix * S > 0x1FFFFFFFull) --S;
+    if ((size_t)nPix * S > 0x1FFFFFFFull) return rtx_fail(RTX_ERR_TOO_LARGE, "more than 2^29 path slots per pass");
     if ((rc = ensure_pool(s, nPix * (uint32_t)S, (size_t)W * H, nPix, usePhotons)) != RTX_OK) return rc;
     PathPoolHost* ph = reinterpret_cast<PathPoolHost*>(s->pool);
     PathPool& pool = ph->dev;
@@ -213,6 +221,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     RTX_HIP(hipMemsetAsync(pool.rayCounters, 0, 8 * sizeof(unsigned long long), st));
     if (s->cfg.counting) RTX_HIP(hipMemsetAsync(s->cfg.counters, 0, 3 * sizeof(unsigned long long), st));
 
+    s->cancel.store(0);
     PassTimers tm{ph};
     int* curPixels = pool.pixels;
     int* nextPixels = pool.pixelsNext;
@@ -221,7 +230,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     for (int round = 0; nPix > 0 && curValid > 0; ++round) {
         const int target = std::min(rp->spp_min, rp->spp_max - roundBase);
         if (target <= 0) break;
-        for (int done = 0; done < target;) {
+        for (int done = 0; done < target && !s->cancel.load(std::memory_order_relaxed);) {
             const int Sp = std::min(S, target - done);
             const int sBase = roundBase + done;
             // ---- one wavefront pass ----
@@ -231,7 +240,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
             launch_raygen(dc, pool, curPixels, nPix, Sp, sBase, stride, qin, pool.counters, st);
             uint32_t n = (uint32_t)(curValid * (size_t)Sp);
             out.paths += n;
-            for (int bounce = 0; bounce < rp->max_bounces && n > 0; ++bounce) {
+            for (int bounce = 0; bounce < rp->max_bounces && n > 0 && !s->cancel.load(std::memory_order_relaxed); ++bounce) {
                 if (bounce == 0) out.rays_primary += n;
                 else out.rays_bounce += n;
                 tm.begin(0, st);
@@ -259,11 +268,14 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                     tm.flush();
                 }
             }
-            launch_film(pool, *film, curPixels, nPix, Sp, W, H, rp->filter_type, rp->filter_radius, (round == 1 && done == 0) ? 1 : 0,
+            // a pass interrupted by rtx_cancel holds unfinished paths: it is dropped, earlier passes stay
+            if (!s->cancel.load(std::memory_order_relaxed))
+                launch_film(pool, *film, curPixels, nPix, Sp, W, H, rp->filter_type, rp->filter_radius, (round == 1 && done == 0) ? 1 : 0,
                         samplesOut, sBase, rp->spp_max, st);
             done += Sp;
         }
         roundBase += target;
+        if (s->cancel.load(std::memory_order_relaxed)) break;
         if (rp->spp_max <= rp->spp_min || roundBase >= rp->spp_max) break;
         // ---- confidence-interval test -> next pixel list ----
         launch_fill_int(nextPixels, nPix, -1, st);
@@ -302,6 +314,12 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
 }
 
 extern "C" {
+
+int rtx_cancel(rtx_scene* s) {
+    if (!s) return rtx_fail(RTX_ERR_INVALID, "scene is NULL");
+    s->cancel.store(1);
+    return RTX_OK;
+}
 
 int rtx_film_clear(const rtx_film* film, int width, int height, void* stream) {
     if (!film || !film->accum || !film->count || !film->z || width <= 0 || height <= 0) return rtx_fail(RTX_ERR_INVALID, "bad film");

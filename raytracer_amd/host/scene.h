@@ -1,0 +1,268 @@
+// Host-side scene types for the C++ mirror of the reference's hot-path interface.
+//
+// The reference compiles against a course framework (scene.h, objects.h, materials.h, lights.h, renderer.h, cy*.h)
+// that is absent from its repository. These are NOT those files: they are the minimal plain types the
+// mirrored entry points (RayCaster, IntersectNode, IntersectSceneWithLights, CollectSceneNodeObjects,
+// ShadeInfoAdapter, PhotonMapBuilder) need in their signatures, with the member names the reference's call sites
+// use. All ray casting and light transport happens on the GPU behind the C ABI (include/rtx.h); nothing here
+// intersects or shades anything.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+#include "../../include/rtx.h"
+
+namespace rtamd {
+
+constexpr float BIGFLOAT = RTX_BIGFLOAT;
+enum { HIT_NONE = 0, HIT_FRONT = 1, HIT_BACK = 2, HIT_FRONT_AND_BACK = 3 };
+
+struct Vec3f {
+    float x = 0, y = 0, z = 0;
+    Vec3f() = default;
+    Vec3f(float a, float b, float c) : x(a), y(b), z(c) {}
+    float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+    Vec3f operator+(Vec3f const& o) const { return {x + o.x, y + o.y, z + o.z}; }
+    Vec3f operator-(Vec3f const& o) const { return {x - o.x, y - o.y, z - o.z}; }
+    Vec3f operator-() const { return {-x, -y, -z}; }
+    Vec3f operator*(float s) const { return {x * s, y * s, z * s}; }
+    Vec3f operator/(float s) const { return {x / s, y / s, z / s}; }
+    float operator%(Vec3f const& o) const { return x * o.x + y * o.y + z * o.z; }                      // dot
+    Vec3f operator^(Vec3f const& o) const { return {y * o.z - z * o.y, z * o.x - x * o.z, x * o.y - y * o.x}; }  // cross
+    float Dot(Vec3f const& o) const { return *this % o; }
+    Vec3f Cross(Vec3f const& o) const { return *this ^ o; }
+    float LengthSquared() const { return *this % *this; }
+    float Length() const { return std::sqrt(LengthSquared()); }
+    void Normalize() { *this = *this / Length(); }
+    Vec3f GetNormalized() const { return *this / Length(); }
+    void Set(float a, float b, float c) { x = a; y = b; z = c; }
+    void Zero() { x = y = z = 0; }
+};
+
+struct Color {
+    float r = 0, g = 0, b = 0;
+    Color() = default;
+    explicit Color(float v) : r(v), g(v), b(v) {}
+    Color(float R, float G, float B) : r(R), g(G), b(B) {}
+};
+struct Color24 {
+    uint8_t r = 0, g = 0, b = 0;
+};
+
+// 3x4 affine transform (row-major), identity by default
+struct Matrix34 {
+    float m[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    static Matrix34 Compose(Matrix34 const& a, Matrix34 const& b) {   // a * b
+        Matrix34 r;
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) r.m[i * 4 + j] = a.m[i * 4] * b.m[j] + a.m[i * 4 + 1] * b.m[4 + j] + a.m[i * 4 + 2] * b.m[8 + j];
+            r.m[i * 4 + 3] = a.m[i * 4] * b.m[3] + a.m[i * 4 + 1] * b.m[7] + a.m[i * 4 + 2] * b.m[11] + a.m[i * 4 + 3];
+        }
+        return r;
+    }
+};
+
+struct Ray {
+    Vec3f p, dir;
+    Ray() = default;
+    Ray(Vec3f const& P, Vec3f const& D) : p(P), dir(D) {}
+};
+
+struct Box {
+    Vec3f pmin{BIGFLOAT, BIGFLOAT, BIGFLOAT}, pmax{-BIGFLOAT, -BIGFLOAT, -BIGFLOAT};
+    bool IsEmpty() const { return pmin.x > pmax.x || pmin.y > pmax.y || pmin.z > pmax.z; }
+};
+
+class Node;
+class Light;
+
+struct HitInfo {
+    float z;
+    Node const* node;
+    Vec3f p, N, GN, uvw, duvw[2], dpdu, dpdv;
+    int mtlID;
+    bool front, light;
+    HitInfo() { Init(); }
+    void Init() {
+        z = BIGFLOAT;
+        node = nullptr;
+        p = N = GN = dpdu = dpdv = Vec3f();
+        uvw = Vec3f(0.5f, 0.5f, 0.5f);
+        duvw[0].Zero();
+        duvw[1].Zero();
+        mtlID = 0;
+        front = true;
+        light = false;
+    }
+};
+
+// ---- textures / materials / lights: parameter holders that are flattened into the rtx_scene_desc ----
+struct TextureMap {
+    int width = 0, height = 0;
+    bool isFloat = false;
+    std::vector<uint8_t> rgb8;     // width*height*3
+    std::vector<float> rgb32f;     // width*height*3
+    Matrix34 itm;                  // texture-space transform applied to uvw before lookup
+};
+struct TexturedColor {
+    Color value{0, 0, 0};
+    std::shared_ptr<TextureMap> map;
+    Color GetValue() const { return value; }
+    TextureMap const* GetTexture() const { return map.get(); }
+};
+
+class Material {
+public:
+    virtual ~Material() = default;
+    virtual int Type() const = 0;
+    TexturedColor diffuse, specular, reflection, refraction, emission;
+    float glossiness = 20.0f, ior = 1.5f;
+    Color absorption{0, 0, 0};
+    std::shared_ptr<TextureMap> bump;
+    float bumpIntensity = 1.0f;
+    TexturedColor const& Diffuse() const { return diffuse; }
+    TexturedColor const& Refraction() const { return refraction; }
+    float IOR(int = 0) const { return ior; }
+    Color Absorption(int = 0) const { return absorption; }
+    bool IsPhotonSurface(int = 0) const { return diffuse.value.r + diffuse.value.g + diffuse.value.b > 0.0f; }
+};
+class MtlBlinn : public Material {
+public:
+    MtlBlinn() { diffuse.value = Color(0.5f); specular.value = Color(0.7f); }
+    int Type() const override { return RTX_MTL_BLINN; }
+};
+class MtlPhong : public Material {
+public:
+    MtlPhong() { diffuse.value = Color(0.5f); specular.value = Color(0.7f); }
+    int Type() const override { return RTX_MTL_PHONG; }
+};
+
+class Light {
+public:
+    virtual ~Light() = default;
+    virtual bool IsRenderable() const { return false; }
+    virtual bool IsPhotonSource() const { return false; }
+};
+class PointLight : public Light {
+public:
+    Vec3f position;
+    Color intensity{1, 1, 1};
+    float size = 0.0f, attenuation = 1.0f;
+    bool IsRenderable() const override { return size > 0.0f; }
+    bool IsPhotonSource() const override { return true; }
+    Color Intensity() const { return intensity; }
+};
+
+// ---- objects and the node tree ----
+class Object {
+public:
+    virtual ~Object() = default;
+    virtual Box GetBoundBox() const = 0;
+};
+
+// Triangle mesh with cy::TriMesh's accessors (V/VN/VT, F/FN/FT); BuildAcceleration only records the bounds: the
+// acceleration structure is built when the scene is flattened for the GPU (objects.cpp:128-138).
+class TriObj : public Object {
+public:
+    struct TriFace {
+        int v[3];
+    };
+    std::vector<Vec3f> v, vn, vt;
+    std::vector<TriFace> f, fn, ft;
+    std::vector<int> faceMtl;
+    unsigned int NF() const { return (unsigned int)f.size(); }
+    bool HasNormals() const { return !vn.empty(); }
+    bool HasTextureVertices() const { return !vt.empty(); }
+    Vec3f const& V(int i) const { return v[i]; }
+    TriFace const& F(int i) const { return f[i]; }
+    int GetMaterialIndex(int face) const { return faceMtl.empty() ? 0 : faceMtl[face]; }
+    void BuildAcceleration() {
+        bounds = Box();
+        for (auto const& p : v) {
+            bounds.pmin = Vec3f(std::fmin(bounds.pmin.x, p.x), std::fmin(bounds.pmin.y, p.y), std::fmin(bounds.pmin.z, p.z));
+            bounds.pmax = Vec3f(std::fmax(bounds.pmax.x, p.x), std::fmax(bounds.pmax.y, p.y), std::fmax(bounds.pmax.z, p.z));
+        }
+    }
+    Box GetBoundBox() const override { return bounds; }
+
+private:
+    Box bounds;
+};
+
+class Node {
+public:
+    Matrix34 tm;   // node -> parent
+    void AppendChild(Node* n) { children.emplace_back(n); }
+    int GetNumChild() const { return (int)children.size(); }
+    Node const* GetChild(int i) const { return children[i].get(); }
+    Node* GetChild(int i) { return children[i].get(); }
+    Object const* GetNodeObj() const { return obj.get(); }
+    void SetNodeObj(std::shared_ptr<Object> o) { obj = std::move(o); }
+    Material const* GetMaterial() const { return mtl.get(); }
+    void SetMaterial(std::shared_ptr<Material> m) { mtl = std::move(m); }
+
+private:
+    std::vector<std::unique_ptr<Node>> children;
+    std::shared_ptr<Object> obj;
+    std::shared_ptr<Material> mtl;
+};
+
+struct Scene {
+    Node rootNode;
+    std::vector<Light*> lights;          // borrowed by the ray caster, owned here
+    std::vector<std::unique_ptr<Light>> lightStorage;
+    TexturedColor environment, background;
+    float backgroundEmission = 0.0f;
+    PointLight* AddPointLight() {
+        lightStorage.emplace_back(new PointLight());
+        lights.push_back(lightStorage.back().get());
+        return static_cast<PointLight*>(lights.back());
+    }
+};
+
+struct Camera {
+    Vec3f pos{0, 0, 0}, dir{0, 0, -1}, up{0, 1, 0};
+    float fov = 40.0f, focaldist = 1.0f, dof = 0.0f;
+    int imgWidth = 200, imgHeight = 150;
+    bool sRGB = false;
+};
+
+// RenderImage: the output arrays CastRays fills (RayCaster.cpp:1000-1012, 1183-1211), row-major y*W+x
+class RenderImage {
+public:
+    void Init(int w, int h) {
+        width = w;
+        height = h;
+        img.assign((size_t)w * h, Color24());
+        zbuffer.assign((size_t)w * h, BIGFLOAT);
+        sampleCount.assign((size_t)w * h, 0);
+        linear.assign((size_t)w * h, Color());
+        albedo.assign((size_t)w * h, Color());
+        normal.assign((size_t)w * h, Vec3f());
+        numRendered = 0;
+    }
+    int GetWidth() const { return width; }
+    int GetHeight() const { return height; }
+    Color24* GetPixels() { return img.data(); }
+    float* GetZBuffer() { return zbuffer.data(); }
+    int* GetSampleCount() { return sampleCount.data(); }
+    Color* GetLinearPixels() { return linear.data(); }
+    Color* GetAlbedo() { return albedo.data(); }
+    Vec3f* GetNormal() { return normal.data(); }
+    void IncrementNumRenderPixel(int n) { numRendered += n; }
+    int GetNumRenderedPixels() const { return numRendered; }
+    void ResetNumRenderedPixels() { numRendered = 0; }
+
+private:
+    int width = 0, height = 0, numRendered = 0;
+    std::vector<Color24> img;
+    std::vector<float> zbuffer;
+    std::vector<int> sampleCount;
+    std::vector<Color> linear, albedo;
+    std::vector<Vec3f> normal;
+};
+
+}  // namespace rtamd

@@ -1,0 +1,274 @@
+// Parity test of the C++ host mirror (raytracer_amd/host/*.h): builds a node tree with the reference's interface,
+// runs IntersectNode / IntersectSceneWithLights / TraceRay / TraceShadowRay / RayCaster::CastRays /
+// PhotonMapBuilder::BuildPhotonMap on the GPU and checks them against the CPU oracle (oracle/liboracle.so), which
+// is linked here as the checker only.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <thread>
+#include "../../raytracer_amd/host/RayCaster.h"
+#include "../../raytracer_amd/host/ShadeInfoAdapter.h"
+
+using namespace rtamd;
+
+extern "C" {
+int orc_scene_create(const rtx_scene_desc* d, void** out);
+void orc_scene_destroy(void* s);
+int orc_trace_closest(void* s, const rtx_ray* rays, size_t n, int hit_side, int with_lights, int use_bvh, rtx_hit* hits, uint64_t* counters);
+int orc_render(void* s, const rtx_camera* cam, const rtx_render_params* rp, void* photons, int nthreads, int subset_stride, float* accum,
+               int* count, float* z, float* albedo, float* normal, float* linear, unsigned char* rgb8, uint64_t* counters, double* secs);
+}
+
+static int failures = 0;
+#define CHECK(cond, ...)                                   \
+    do {                                                   \
+        if (!(cond)) {                                     \
+            std::printf("FAIL %s:%d: ", __FILE__, __LINE__); \
+            std::printf(__VA_ARGS__);                      \
+            std::printf("\n");                             \
+            ++failures;                                    \
+        }                                                  \
+    } while (0)
+
+static std::shared_ptr<TriObj> MakeTorus(float R, float r, int nu, int nv) {
+    auto t = std::make_shared<TriObj>();
+    for (int i = 0; i <= nu; ++i)
+        for (int j = 0; j <= nv; ++j) {
+            float a = 6.2831853f * i / nu, b = 6.2831853f * j / nv;
+            t->v.push_back(Vec3f((R + r * std::cos(b)) * std::cos(a), r * std::sin(b), (R + r * std::cos(b)) * std::sin(a)));
+            t->vn.push_back(Vec3f(std::cos(b) * std::cos(a), std::sin(b), std::cos(b) * std::sin(a)));
+            t->vt.push_back(Vec3f((float)i / nu, (float)j / nv, 0));
+        }
+    for (int i = 0; i < nu; ++i)
+        for (int j = 0; j < nv; ++j) {
+            int a = i * (nv + 1) + j, b = (i + 1) * (nv + 1) + j, c = b + 1, d = a + 1;
+            t->f.push_back({{c, b, a}});
+            t->f.push_back({{d, c, a}});
+        }
+    t->fn = t->f;
+    t->ft = t->f;
+    t->BuildAcceleration();
+    return t;
+}
+
+int main() {
+    if (rtx_device_count() <= 0) {
+        std::printf("no HIP device\n");
+        return 2;
+    }
+    // scene graph: root -> {torus A (identity), group (translated) -> {torus B (scaled), glass torus C}}, floor
+    Scene scene;
+    auto red = std::make_shared<MtlBlinn>();
+    red->diffuse.value = Color(0.7f, 0.1f, 0.1f);
+    auto glass = std::make_shared<MtlBlinn>();
+    glass->diffuse.value = Color(0, 0, 0);
+    glass->specular.value = Color(0, 0, 0);
+    glass->refraction.value = Color(1, 1, 1);
+    glass->glossiness = 1e5f;
+    glass->absorption = Color(0.75f, 0.15f, 0.15f);
+    auto white = std::make_shared<MtlBlinn>();
+    white->diffuse.value = Color(0.8f, 0.8f, 0.8f);
+    auto torus = MakeTorus(1.0f, 0.35f, 48, 24);
+    Node* a = new Node();
+    a->SetNodeObj(torus);
+    a->SetMaterial(red);
+    scene.rootNode.AppendChild(a);
+    Node* grp = new Node();
+    grp->tm.m[3] = 2.5f;
+    grp->tm.m[7] = 0.3f;
+    scene.rootNode.AppendChild(grp);
+    Node* b = new Node();
+    b->SetNodeObj(torus);
+    b->SetMaterial(white);
+    b->tm.m[0] = 0.5f; b->tm.m[5] = 0.5f; b->tm.m[10] = 0.5f;
+    grp->AppendChild(b);
+    Node* c = new Node();
+    c->SetNodeObj(torus);
+    c->SetMaterial(glass);
+    c->tm.m[7] = 1.2f;
+    grp->AppendChild(c);
+    auto floorObj = std::make_shared<TriObj>();
+    floorObj->v = {Vec3f(-8, -0.4f, -8), Vec3f(8, -0.4f, -8), Vec3f(8, -0.4f, 8), Vec3f(-8, -0.4f, 8)};
+    floorObj->f = {{{0, 2, 1}}, {{0, 3, 2}}};
+    floorObj->BuildAcceleration();
+    Node* fl = new Node();
+    fl->SetNodeObj(floorObj);
+    fl->SetMaterial(white);
+    scene.rootNode.AppendChild(fl);
+    PointLight* L = scene.AddPointLight();
+    L->position = Vec3f(1, 6, 2);
+    L->intensity = Color(20, 18, 15);
+    L->size = 0.8f;
+    scene.environment.value = Color(0.3f, 0.35f, 0.4f);
+
+    // CollectSceneNodeObjects: DFS pre-order (SceneAdapter.h:8-18)
+    std::vector<std::pair<const Node*, const Object*>> no;
+    CollectSceneNodeObjects(scene, no);
+    CHECK(no.size() == 4 && no[0].first == a && no[1].first == b && no[2].first == c && no[3].first == fl, "DFS order");
+
+    // the same flattened description for the oracle
+    std::vector<rtx_mesh_desc> meshes;
+    std::vector<rtx_material_desc> mtls(3);
+    auto setm = [](rtx_material_desc& d, const Material& m) {
+        d = rtx_material_desc{};
+        d.type = m.Type();
+        const Color* src[5] = {&m.diffuse.value, &m.specular.value, &m.reflection.value, &m.refraction.value, &m.emission.value};
+        float* dst[5] = {d.diffuse, d.specular, d.reflection, d.refraction, d.emission};
+        for (int k = 0; k < 5; ++k) { dst[k][0] = src[k]->r; dst[k][1] = src[k]->g; dst[k][2] = src[k]->b; }
+        d.diffuse_tex = d.specular_tex = d.reflection_tex = d.refraction_tex = d.emission_tex = d.bump_tex = -1;
+        d.glossiness = m.glossiness; d.ior = m.ior; d.bump_scale = 1;
+        d.absorption[0] = m.absorption.r; d.absorption[1] = m.absorption.g; d.absorption[2] = m.absorption.b;
+    };
+    setm(mtls[0], *red); setm(mtls[1], *white); setm(mtls[2], *glass);
+    const Matrix34 worlds[4] = {a->tm, Matrix34::Compose(grp->tm, b->tm), Matrix34::Compose(grp->tm, c->tm), fl->tm};
+    const int mi[4] = {0, 1, 2, 1};
+    for (int k = 0; k < 4; ++k) {
+        auto t = static_cast<const TriObj*>(no[k].second);
+        rtx_mesh_desc d{};
+        d.v = &t->v.data()->x; d.nv = (int)t->v.size();
+        d.vn = t->vn.empty() ? nullptr : &t->vn.data()->x; d.nvn = (int)t->vn.size();
+        d.vt = t->vt.empty() ? nullptr : &t->vt.data()->x; d.nvt = (int)t->vt.size();
+        d.f = t->f.data()->v; d.nf = (int)t->f.size();
+        for (int q = 0; q < 12; ++q) d.xform[q] = worlds[k].m[q];
+        d.material = mi[k];
+        meshes.push_back(d);
+    }
+    rtx_light_desc ld{{1, 6, 2}, {20, 18, 15}, 0.8f, 1.0f};
+    rtx_scene_desc sd{};
+    sd.meshes = meshes.data(); sd.n_meshes = 4;
+    sd.materials = mtls.data(); sd.n_materials = 3;
+    sd.lights = &ld; sd.n_lights = 1;
+    sd.environment[0] = 0.3f; sd.environment[1] = 0.35f; sd.environment[2] = 0.4f;
+    sd.environment_tex = sd.background_tex = -1;
+    void* osc = nullptr;
+    orc_scene_create(&sd, &osc);
+
+    // IntersectNode / IntersectSceneWithLights per ray and batched, all hit sides
+    std::mt19937 rng(7);
+    std::uniform_real_distribution<float> U(-1, 1);
+    const int N = 4000;
+    std::vector<Ray> rays(N);
+    std::vector<rtx_ray> rr(N);
+    for (int i = 0; i < N; ++i) {
+        Vec3f o(4 * U(rng) + 1, 3 * U(rng) + 1, 4 * U(rng)), t(2 * U(rng) + 1, U(rng), 2 * U(rng));
+        rays[i] = Ray(o, (t - o).GetNormalized());
+        rr[i] = detail::ToRay(rays[i], BIGFLOAT);
+    }
+    for (int side = HIT_FRONT; side <= HIT_FRONT_AND_BACK; ++side) {
+        std::vector<rtx_hit> oh(N);
+        orc_trace_closest(osc, rr.data(), N, side, 1, 1, oh.data(), nullptr);
+        std::vector<ExtendedHitInfo> hits(N);
+        for (auto& h : hits) h.Init();
+        std::vector<bool> flags;
+        IntersectSceneBatch(&scene, rays, hits, side, true, &flags);
+        int mism = 0, nhit = 0;
+        for (int i = 0; i < N; ++i) {
+            bool ohit = oh[i].obj >= 0 || oh[i].light >= 0;
+            if (flags[i] != ohit) { ++mism; continue; }
+            if (!ohit) continue;
+            ++nhit;
+            const Node* expect = oh[i].obj >= 0 ? no[oh[i].obj].first : nullptr;
+            if (hits[i].node != expect || (hits[i].hitLight != nullptr) != (oh[i].light >= 0)) ++mism;
+            else if (std::fabs(hits[i].z - oh[i].t) > 1e-4f * oh[i].t) ++mism;
+        }
+        CHECK(mism <= N / 500 && nhit > N / 10, "side %d: %d mismatches of %d (%d hits)", side, mism, N, nhit);
+    }
+    {   // single-ray entry points
+        ExtendedHitInfo e; e.Init();
+        rtx_hit oh;
+        orc_trace_closest(osc, &rr[0], 1, HIT_FRONT_AND_BACK, 1, 1, &oh, nullptr);
+        bool hit = IntersectSceneWithLights(&scene, rays[0], e, HIT_FRONT_AND_BACK);
+        CHECK(hit == (oh.obj >= 0 || oh.light >= 0), "IntersectSceneWithLights hit flag");
+        HitInfo h; h.Init();
+        bool hn = IntersectNode(&scene.rootNode, rays[1], h, HIT_FRONT_AND_BACK);
+        orc_trace_closest(osc, &rr[1], 1, HIT_FRONT_AND_BACK, 0, 1, &oh, nullptr);
+        CHECK(hn == (oh.obj >= 0) && (!hn || std::fabs(h.z - oh.t) <= 1e-4f * oh.t), "IntersectNode");
+        // in-out bound (IntersectNodeAdapter.h:103): a bound below the hit distance means no hit
+        if (hn) {
+            HitInfo h2; h2.Init(); h2.z = h.z * 0.5f;
+            CHECK(!IntersectNode(&scene.rootNode, rays[1], h2, HIT_FRONT_AND_BACK) && h2.z == h.z * 0.5f, "bound in-out");
+        }
+        // sub-tree query: IntersectNode on the group node sees only B and C
+        HitInfo hg; hg.Init();
+        Ray down(Vec3f(2.5f + 0.5f, 5, 0), Vec3f(0, -1, 0));
+        CHECK(IntersectNode(grp, down, hg, HIT_FRONT_AND_BACK) && (hg.node == b || hg.node == c), "sub-tree IntersectNode");
+        HitInfo ht;
+        CHECK(TraceRay(scene, down, ht) && ht.node == hg.node && std::fabs(ht.z - hg.z) < 1e-4f, "TraceRay");
+        CHECK(TraceShadowRay(scene, down, ht.z * 0.5f) && !TraceShadowRay(scene, down, ht.z * 2.0f), "TraceShadowRay");
+        ShadeInfoAdapter si(scene.lights, &scene);
+        HitInfo fh; fh.Init(); fh.p = Vec3f(2.5f + 0.5f, -0.4f, 0); fh.N = Vec3f(0, 1, 0); fh.node = fl;
+        si.SetHit(Ray(Vec3f(0, 3, 0), Vec3f(0, -1, 0)), fh);
+        CHECK(si.TraceShadowRay(Vec3f(0, 1, 0), 10.0f) == 0.0f, "legacy shadow ray is blocked by the tori above");
+        CHECK(si.TraceShadowRay(Vec3f(0, 1, 0), 0.2f) == 1.0f, "legacy shadow ray: segment ends before the blocker");
+    }
+
+    // RayCaster::CastRays against the oracle render (fixed 8 spp), then adaptive, then Stop()
+    Camera cam;
+    cam.pos = Vec3f(0.5f, 2.5f, 6.5f);
+    cam.dir = (Vec3f(1.2f, 0.3f, 0) - cam.pos).GetNormalized();
+    Vec3f x = cam.dir ^ Vec3f(0, 1, 0);
+    cam.up = (x ^ cam.dir).GetNormalized();
+    cam.fov = 35; cam.focaldist = 6.5f; cam.dof = 0.03f; cam.imgWidth = 96; cam.imgHeight = 64; cam.sRGB = true;
+    RayCaster rc(&scene, &cam);
+    rc.sampling.minSamples = rc.sampling.maxSamples = 8;
+    RenderImage img;
+    img.Init(cam.imgWidth, cam.imgHeight);
+    rc.CastRays(img);
+    rtx_camera ocam{};
+    ocam.pos[0] = cam.pos.x; ocam.pos[1] = cam.pos.y; ocam.pos[2] = cam.pos.z;
+    ocam.dir[0] = cam.dir.x; ocam.dir[1] = cam.dir.y; ocam.dir[2] = cam.dir.z;
+    ocam.up[0] = cam.up.x; ocam.up[1] = cam.up.y; ocam.up[2] = cam.up.z;
+    ocam.fov = cam.fov; ocam.focaldist = cam.focaldist; ocam.dof = cam.dof; ocam.width = 96; ocam.height = 64; ocam.srgb = 1;
+    rtx_render_params rp{};
+    rp.spp_min = rp.spp_max = 8; rp.index_stride = 1024; rp.ci_halfwidth = 0.005f; rp.filter_type = 0; rp.filter_radius = 1.0f;
+    rp.max_bounces = 64; rp.seed = 0x9e3779b97f4a7c15ULL; rp.tile_size = 16; rp.world = 1;
+    const size_t np = 96 * 64;
+    std::vector<float> lin(np * 3), z(np);
+    std::vector<int> cnt(np);
+    std::vector<unsigned char> rgb(np * 3);
+    orc_render(osc, &ocam, &rp, nullptr, 4, 1, nullptr, cnt.data(), z.data(), nullptr, nullptr, lin.data(), rgb.data(), nullptr, nullptr);
+    double se = 0, mean = 0;
+    int zbad = 0;
+    for (size_t i = 0; i < np; ++i) {
+        const Color& g = img.GetLinearPixels()[i];
+        se += std::pow(g.r - lin[3 * i], 2) + std::pow(g.g - lin[3 * i + 1], 2) + std::pow(g.b - lin[3 * i + 2], 2);
+        mean += lin[3 * i] + lin[3 * i + 1] + lin[3 * i + 2];
+        if (std::fabs(img.GetZBuffer()[i] - z[i]) > 1e-4f * std::fabs(z[i])) ++zbad;
+        if (img.GetSampleCount()[i] != cnt[i]) ++zbad;
+    }
+    double rmse = std::sqrt(se / (3 * np));
+    mean /= 3 * np;
+    CHECK(rmse <= 0.02 * mean && zbad <= (int)np / 1000, "CastRays: rmse %.5f mean %.5f zbad %d", rmse, mean, zbad);
+    CHECK(img.GetNumRenderedPixels() == (int)np, "rendered pixel counter");
+
+    // photon map through the mirrored builder
+    PhotonMapBuilder pmb;
+    pmb.SetNumPhotons(200000);
+    pmb.BuildPhotonMap(&scene);
+    CHECK(pmb.GetPhotonMap()->NumPhotons() > 0, "global photon map is populated");
+    CHECK(pmb.GetCausticSearchRadius() >= 0.01f && pmb.GetPhotonSearchRadius() >= 0.05f, "gather radii");
+    RenderImage img2;
+    img2.Init(cam.imgWidth, cam.imgHeight);
+    rc.CastRays(img2, &pmb);
+
+    // Stop() from another thread ends a long render early
+    rc.sampling.minSamples = rc.sampling.maxSamples = 1024;
+    RenderImage img3;
+    img3.Init(cam.imgWidth, cam.imgHeight);
+    std::thread stopper([&] {
+        std::this_thread::sleep_for(std::chrono::milliseconds(30));
+        rc.Stop();
+    });
+    rc.CastRays(img3);
+    stopper.join();
+    CHECK(rc.IsStopped(), "IsStopped after Stop()");
+    long total = 0;
+    for (size_t i = 0; i < np; ++i) total += img3.GetSampleCount()[i];
+    CHECK(total < (long)np * 1024, "cancelled render took fewer samples (%ld)", total);
+
+    ReleaseGpuScenes();
+    orc_scene_destroy(osc);
+    std::printf(failures ? "host_parity: %d FAILURES\n" : "host_parity: all checks passed\n", failures);
+    return failures ? 1 : 0;
+}
