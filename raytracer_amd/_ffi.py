@@ -113,7 +113,8 @@ def np_dtypes():
 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtx_amd.so")
+# RTX_AMD_LIB selects another build of the same library (A/B runs of kernel variants, tools/build_variant.sh)
+LIB_PATH = os.environ.get("RTX_AMD_LIB") or os.path.join(_HERE, "librtx_amd.so")
 
 # every symbol include/rtx.h declares: (name, restype, argtypes)
 _vp = C.c_void_p

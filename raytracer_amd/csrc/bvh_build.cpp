@@ -161,7 +161,9 @@ inline void invert34(const float* M, float* R) {
     }
 }
 
-inline float decode_q(float o, int q, float scale) { return std::fmaf((float)q, scale, o); }
+// exact position of quantised plane q (the kernels test rays in the node's quantised frame, where planes sit at
+// exactly o + q*scale)
+inline double decode_q(float o, int q, float scale) { return (double)o + (double)q * (double)scale; }
 
 struct Emitter {
     const Builder& B;
@@ -256,6 +258,15 @@ struct Emitter {
         nd.ox = n.box.lo[0]; nd.oy = n.box.lo[1]; nd.oz = n.box.lo[2];
         const float o[3] = {nd.ox, nd.oy, nd.oz};
         uint8_t* ebytes[3] = {&nd.ex, &nd.ey, &nd.ez};
+        int Efloor = 30;
+        for (int a = 0; a < 3; ++a) {
+            float extent = n.box.hi[a] - n.box.lo[a];
+            if (extent > 0.0f) {
+                int e;
+                std::frexp(extent / 255.0f, &e);
+                Efloor = std::max(Efloor, e + 127 - 40);
+            }
+        }
         for (int a = 0; a < 3; ++a) {
             float extent = n.box.hi[a] - n.box.lo[a];
             int E = 1;
@@ -264,9 +275,11 @@ struct Emitter {
                 std::frexp(extent / 255.0f, &e);  // extent/255 = m * 2^e, m in [0.5,1)
                 E = e + 127;
             }
-            if (E < 1) E = 1;
+            // flat or tiny axes: keep 2^-E and (ray origin - o) * 2^-E well inside the float range (the kernels work
+            // in the quantised frame), so never go below 2^-40 of the node's largest quantisation step
+            if (E < Efloor) E = Efloor;
             for (;; ++E) {
-                if (E > 254) {
+                if (E > 253) {  // the kernels also need 2^-E (biased exponent 254-E) as a normal float
                     err = "scene extent too large to quantise";
                     return my;
                 }
@@ -478,7 +491,7 @@ struct Validator {
                 uint32_t bits = (uint32_t)e[a] << 23;
                 float scale;
                 std::memcpy(&scale, &bits, 4);
-                float lo = decode_q(o[a], n.qlo[a][i], scale), hi = decode_q(o[a], n.qhi[a][i], scale);
+                double lo = decode_q(o[a], n.qlo[a][i], scale), hi = decode_q(o[a], n.qhi[a][i], scale);
                 // v1/v2 are re-derived as v0+e (one rounding each), allow that slack
                 float slack = 4e-7f * std::max(std::fabs(cb.lo[a]), std::fabs(cb.hi[a])) + 1e-30f;
                 if (lo > cb.lo[a] + slack || hi < cb.hi[a] - slack) {

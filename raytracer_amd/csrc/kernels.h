@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "layout.h"
+#include "segqueue.h"
 #include "../../include/rtx.h"
 
 // Camera with the per-frame constants of RayCaster.cpp:717-724 / CameraAdapter.h:8-21 evaluated once on the host.
@@ -20,6 +21,7 @@ struct LaunchCfg {
     int gridBlocks;          // persistent grid: CUs x resident blocks
     uint2* spill;            // gridBlocks*256*STACK_GLOBAL entries
     uint32_t* workCounter;   // zeroed before every launch that fetches work dynamically
+    SegQ identQ;             // control words of the identity queue used by plain ray batches
     unsigned long long* counters;  // [0] nodes, [1] tris, [2] rays (only with counting)
     hipStream_t stream;
     int counting;
@@ -27,7 +29,12 @@ struct LaunchCfg {
 
 // extend: closest hit for n rays (rtx_ray layout, 2 x float4) -> hits float4 {t,u,v,bits(slot)}
 void launch_extend(const DevScene& sc, const LaunchCfg& cfg, const float4* rays, uint32_t n, int hitSide, int withLights,
-                   float4* hits, const uint32_t* queue = nullptr);
+                   float4* hits);
+// the same for the n rays whose indices are the entries of a segmented queue (items == nullptr: identity)
+void launch_extend_queue(const DevScene& sc, const LaunchCfg& cfg, const float4* rays, const SegQ& q, const uint32_t* items,
+                         uint32_t n, int hitSide, int withLights, float4* hits);
+void launch_segq_scan2(const SegQ& qa, uint32_t Ga, uint32_t multA, const SegQ& qb, uint32_t Gb, uint32_t multB, uint32_t blockThreads,
+                       uint32_t* totals, hipStream_t stream);
 // CameraAdapter.h:7-27 pixel-centre rays for the whole image
 void launch_primary_raygen(const DevCamera& cam, float4* rays, hipStream_t stream);
 // compact hit -> full rtx_hit (device array)
@@ -42,13 +49,15 @@ int query_resident_blocks(int which);  // blocks per CU for kernel 'which' (0 ex
 // ---- wavefront path tracing (kernels_path.hip) ----
 struct PathPool;
 struct DevPhotonMap;
-void launch_raygen(const DevCamera& cam, const PathPool& pool, const int* pixels, uint32_t nPix, int S, int sBase, int indexStride,
-                   uint32_t* queueOut, uint32_t* counters, hipStream_t stream);
-void launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm, const uint32_t* queueIn,
-                  uint32_t n, int bounce, int maxBounces, unsigned long long seed, int sBase, int S, const int* pixels,
-                  uint32_t* queueOut, uint32_t* counters, hipStream_t stream);
-void launch_shadow(const DevScene& sc, const LaunchCfg& cfg, const PathPool& pool, uint32_t n, int useTransmittance);
-void launch_resolve(const PathPool& pool, const uint32_t* queueIn, uint32_t n, int nLights, int usePhotons, hipStream_t stream);
+// raygen and shade return their grid size: the geometry segq_scan needs for the queues they append to
+uint32_t launch_raygen(const DevCamera& cam, const PathPool& pool, const int* pixels, uint32_t nPix, int S, int sBase, int indexStride,
+                       const SegQ& qOut, uint32_t* queueOut, hipStream_t stream);
+uint32_t launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm, const SegQ& qIn,
+                      const uint32_t* queueIn, uint32_t n, int bounce, int maxBounces, unsigned long long seed, int sBase, int S,
+                      const int* pixels, const SegQ& qOut, uint32_t* queueOut, const SegQ& qShadow, hipStream_t stream);
+void launch_shadow(const DevScene& sc, const LaunchCfg& cfg, const PathPool& pool, const SegQ& q, uint32_t n, int useTransmittance);
+void launch_resolve(const PathPool& pool, const SegQ& qIn, const uint32_t* queueIn, uint32_t n, int nLights, int usePhotons,
+                    hipStream_t stream);
 void launch_film(const PathPool& pool, const rtx_film& film, const int* pixels, uint32_t nPix, int S, int W, int H, int filterType,
                  float filterRadius, int resetZ, float4* samplesOut, int sBase, int sppTotal, hipStream_t stream);
 void launch_adaptive(const PathPool& pool, const int* pixels, uint32_t nPix, float maxHalf, int sppMax, int* pixelsNext,

@@ -7,6 +7,7 @@
 #include "bsdf.h"
 #include "shadow.h"
 #include "photon_gather.h"
+#include "segqueue.h"
 
 // ---- wave-level queue append -------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
@@ -49,7 +50,7 @@ __device__ __forceinline__ void pixel_shifts(int x, int y, float& sx, float& sy)
 }
 
 __global__ void raygen_kernel(DevCamera cam, PathPool pool, const int* __restrict__ pixels, uint32_t nPix, int S, int sBase,
-                              int indexStride, uint32_t* __restrict__ queueOut, uint32_t* counters) {
+                              int indexStride, SegQ qOut, uint32_t* __restrict__ queueOut) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nSlots = nPix * (uint32_t)S;
     bool valid = false;
@@ -105,7 +106,7 @@ __global__ void raygen_kernel(DevCamera cam, PathPool pool, const int* __restric
             pool.samplePos[slot] = make_float2(samplePosX, samplePosY);
         }
     }
-    const uint32_t q = wave_append(valid, &counters[0]);
+    const uint32_t q = segq_append(qOut, valid, 1u);
     if (valid) queueOut[q] = slot;
 }
 
@@ -147,17 +148,24 @@ __device__ __forceinline__ bool has_map_or_value(const float* c, int tex) {   //
 
 // One bounce of TracePath (RayCaster.cpp:359-567) for every path in queueIn. Paths that continue are appended to
 // queueOut; NEE shadow segments are appended to the shadow queue; their results are folded in by resolve_kernel.
-__global__ __launch_bounds__(256) void shade_kernel(DevScene sc, DevCamera cam, PathPool pool, DevPhotonMap pm,
-                                                    const uint32_t* __restrict__ queueIn, uint32_t n, int bounce,
+#ifndef SHADE_WAVES_PER_EU
+#define SHADE_WAVES_PER_EU 2
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES_PER_EU))) void shade_kernel(DevScene sc, DevCamera cam, PathPool pool, DevPhotonMap pm,
+                                                    SegQ qIn, const uint32_t* __restrict__ queueIn, uint32_t n, int bounce,
                                                     int maxBounces, unsigned long long seed, int sBase, int S,
-                                                    const int* __restrict__ pixels, uint32_t* __restrict__ queueOut,
-                                                    uint32_t* counters) {
+                                                    const int* __restrict__ pixels, SegQ qOut, uint32_t* __restrict__ queueOut,
+                                                    SegQ qShadow) {
+    __shared__ uint32_t qtab[SEGQ_TABLE_WORDS];
+    segq_load_table(qIn, qtab);
+    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool alive = false;
     uint32_t slot = 0;
     const uint32_t cap = pool.capacity;
+    const uint32_t shadowMult = (uint32_t)max(1, sc.n_lights);
     if (i < n) {
-        slot = queueIn[i];
+        slot = queueIn[segq_item_index(qtab, i)];
         const float4 ra = pool.rays[2 * (size_t)slot], rb = pool.rays[2 * (size_t)slot + 1];
         const float4 hv = pool.hits[slot];
         RayT ray{ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, ra.w};
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(256) void shade_kernel(DevScene sc, DevCamera cam, 
                         contrib = make_float4(c.x, c.y, c.z, 0.0f);
                         pending = true;
                         // wave-wide append of the lanes that reach this point (ballot counts active lanes only)
-                        const uint32_t qs = wave_append(true, &counters[1]);
+                        const uint32_t qs = segq_append(qShadow, true, shadowMult);
                         const f3 so = offset_point(sh.p, sx.GN, ldir);
                         const f3 sd = safe_normalize3(ldir);
                         pool.shadowQ[2 * (size_t)qs] = make_float4(so.x, so.y, so.z, shadowMax);
@@ -361,42 +369,86 @@ __global__ __launch_bounds__(256) void shade_kernel(DevScene sc, DevCamera cam, 
         }
     }
     // ---- surviving paths -> next queue ----
-    const uint32_t q = wave_append(alive, &counters[0]);
+    const uint32_t q = segq_append(qOut, alive, 1u);
     if (alive) queueOut[q] = slot;
 }
 
 // ---- shadow --------------------------------------------------------------------------------------------------
 // Visible() for every queued NEE segment (RayCaster.cpp:465): writes the transmittance next to its contribution.
-__global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene sc, PathPool pool, uint32_t n, int useTransmittance,
-                                                            uint32_t* workCounter, uint2* spill) {
+// Same structure as the extend kernel (persistent waves, per-lane refill from the segmented queue, while-while
+// traversal); a lane keeps its segment over the hops of the transmittance chain.
+#ifndef SHADOW_REFILL_MIN
+#define SHADOW_REFILL_MIN 16
+#endif
+__global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene sc, PathPool pool, SegQ q, int useTransmittance, uint2* spill,
+                                                            uint32_t chunk) {
     __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
-    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
     TravStack st{&lds_stack[threadIdx.x], spill + gtid, gridDim.x * blockDim.x};
-    uint32_t hops = 0, nc = 0, tc = 0;
+    uint32_t hops = 0;
+    TravState s;
+    s.cur = RTX_TRAV_DONE;
+    s.sp = 0;
+    bool active = false, exhausted = false;
+    SegWalk walk;
+    segq_walk_init(q, walk, gtid >> 6, chunk);
+    uint32_t code = 0;
+    f3 o = mk3(0.0f), d = mk3(0.0f);
+    float maxDist = 0.0f, visibility = 1.0f;
+    int hop = 0;
     for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(workCounter, 64u);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= n) break;
-        const uint32_t i = base + lane;
-        if (i < n) {
-            const float4 a = pool.shadowQ[2 * (size_t)i], b = pool.shadowQ[2 * (size_t)i + 1];
-            const uint32_t code = __float_as_uint(b.w);
-            const uint32_t slot = code >> 3, l = code & 7u;
-            const float T = visible_chain_from<false>(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, useTransmittance != 0, st,
-                                                      &hops, &nc, &tc);
-            pool.nee[(size_t)l * pool.capacity + slot].w = T;
+        const unsigned long long idle = __ballot(!active);
+        const uint32_t nIdle = (uint32_t)__popcll(idle);
+        if (!exhausted && (nIdle >= SHADOW_REFILL_MIN || nIdle == 64u)) {
+            uint32_t first = 0;
+            const uint32_t got = segq_take(q, walk, nIdle, first);
+            if (got == 0u) exhausted = true;
+            if (!active) {
+                const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (prefix < got) {
+                    const size_t e = first + prefix;
+                    const float4 a = pool.shadowQ[2 * e], b = pool.shadowQ[2 * e + 1];
+                    code = __float_as_uint(b.w);
+                    o = mk3(a.x, a.y, a.z);
+                    d = mk3(b.x, b.y, b.z);
+                    maxDist = a.w;
+                    visibility = 1.0f;
+                    hop = 0;
+                    trav_init(s, sc, RayT{o.x, o.y, o.z, d.x, d.y, d.z, maxDist});
+                    hops++;
+                    active = true;
+                }
+            }
+        }
+        if (__ballot(active) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        while (active && trav_is_inner(s.cur)) trav_inner_step(s, sc, st);
+        if (active && s.cur != RTX_TRAV_DONE) trav_leaf_step(s, sc, st, RTX_HIT_FRONT_AND_BACK);
+        if (active && s.cur == RTX_TRAV_DONE) {
+            intersect_lights(sc, s.r, s.best);
+            float T;
+            if (shadow_hop_end(sc, o, d, maxDist, s.best, useTransmittance != 0, hop, visibility, T)) {
+                pool.nee[(size_t)(code & 7u) * pool.capacity + (code >> 3)].w = T;
+                active = false;
+            } else {
+                trav_init(s, sc, RayT{o.x, o.y, o.z, d.x, d.y, d.z, maxDist});
+                hops++;
+            }
         }
     }
     atomicAdd(&pool.rayCounters[0], (unsigned long long)hops);
 }
 
 // ---- resolve: L += beta * sum_i c_i T_i  and the caustic term (RayCaster.cpp:470-522) ------------------------
-__global__ void resolve_kernel(PathPool pool, const uint32_t* __restrict__ queueIn, uint32_t n, int nLights, int usePhotons) {
+__global__ void resolve_kernel(PathPool pool, SegQ qIn, const uint32_t* __restrict__ queueIn, uint32_t n, int nLights, int usePhotons) {
+    __shared__ uint32_t qtab[SEGQ_TABLE_WORDS];
+    segq_load_table(qIn, qtab);
+    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t slot = queueIn[i];
+    const uint32_t slot = queueIn[segq_item_index(qtab, i)];
     const float4 pb = pool.pendBeta[slot];
     if (pb.w < 0.0f) return;
     const f3 beta = mk3(pb.x, pb.y, pb.z);
@@ -614,31 +666,34 @@ __global__ void film_resolve_kernel(rtx_film film, uint32_t n, int srgb, float* 
 }
 
 // ---- launch wrappers -------------------------------------------------------------------------------------------
-void launch_raygen(const DevCamera& cam, const PathPool& pool, const int* pixels, uint32_t nPix, int S, int sBase, int indexStride,
-                   uint32_t* queueOut, uint32_t* counters, hipStream_t stream) {
+uint32_t launch_raygen(const DevCamera& cam, const PathPool& pool, const int* pixels, uint32_t nPix, int S, int sBase, int indexStride,
+                       const SegQ& qOut, uint32_t* queueOut, hipStream_t stream) {
     const uint32_t n = nPix * (uint32_t)S;
-    if (!n) return;
-    hipLaunchKernelGGL(raygen_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cam, pool, pixels, nPix, S, sBase, indexStride,
-                       queueOut, counters);
+    if (!n) return 0;
+    const uint32_t grid = (n + 255) / 256;
+    hipLaunchKernelGGL(raygen_kernel, dim3(grid), dim3(256), 0, stream, cam, pool, pixels, nPix, S, sBase, indexStride, qOut, queueOut);
+    return grid;
 }
-void launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm, const uint32_t* queueIn,
-                  uint32_t n, int bounce, int maxBounces, unsigned long long seed, int sBase, int S, const int* pixels,
-                  uint32_t* queueOut, uint32_t* counters, hipStream_t stream) {
-    if (!n) return;
-    hipLaunchKernelGGL(shade_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sc, cam, pool, pm, queueIn, n, bounce, maxBounces,
-                       seed, sBase, S, pixels, queueOut, counters);
+uint32_t launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm, const SegQ& qIn,
+                      const uint32_t* queueIn, uint32_t n, int bounce, int maxBounces, unsigned long long seed, int sBase, int S,
+                      const int* pixels, const SegQ& qOut, uint32_t* queueOut, const SegQ& qShadow, hipStream_t stream) {
+    if (!n) return 0;
+    const uint32_t grid = (n + 255) / 256;
+    hipLaunchKernelGGL(shade_kernel, dim3(grid), dim3(256), 0, stream, sc, cam, pool, pm, qIn, queueIn, n, bounce, maxBounces, seed, sBase,
+                       S, pixels, qOut, queueOut, qShadow);
+    return grid;
 }
-void launch_shadow(const DevScene& sc, const LaunchCfg& cfg, const PathPool& pool, uint32_t n, int useTransmittance) {
+void launch_shadow(const DevScene& sc, const LaunchCfg& cfg, const PathPool& pool, const SegQ& q, uint32_t n, int useTransmittance) {
     if (!n) return;
-    (void)hipMemsetAsync(cfg.workCounter, 0, sizeof(uint32_t), cfg.stream);
     const uint32_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
     const uint32_t grid = need < (uint32_t)cfg.gridBlocks ? need : (uint32_t)cfg.gridBlocks;
-    hipLaunchKernelGGL(shadow_kernel, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, pool, n, useTransmittance, cfg.workCounter,
-                       cfg.spill);
+    hipLaunchKernelGGL(shadow_kernel, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, pool, q, useTransmittance, cfg.spill,
+                       segq_chunk(n, grid * (TRAV_BLOCK / 64)));
 }
-void launch_resolve(const PathPool& pool, const uint32_t* queueIn, uint32_t n, int nLights, int usePhotons, hipStream_t stream) {
+void launch_resolve(const PathPool& pool, const SegQ& qIn, const uint32_t* queueIn, uint32_t n, int nLights, int usePhotons,
+                    hipStream_t stream) {
     if (!n) return;
-    hipLaunchKernelGGL(resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pool, queueIn, n, nLights, usePhotons);
+    hipLaunchKernelGGL(resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pool, qIn, queueIn, n, nLights, usePhotons);
 }
 void launch_film(const PathPool& pool, const rtx_film& film, const int* pixels, uint32_t nPix, int S, int W, int H, int filterType,
                  float filterRadius, int resetZ, float4* samplesOut, int sBase, int sppTotal, hipStream_t stream) {

@@ -3,33 +3,114 @@
 // citations.
 #include "kernels.h"
 #include "shadow.h"
+#include "segqueue.h"
 
-// Each wave pulls 64 consecutive rays at a time from a global cursor, so neighbouring (coherent) rays share a
-// wave and waves stay busy until the queue is drained; every wave leaves the loop once the cursor passes n.
+// ---- segmented queue control (segqueue.h) ---------------------------------------------------------------------
+// One wave per queue: lane s owns segment s.
+__global__ void segq_scan_kernel(SegQ qa, uint32_t Ga, uint32_t Ba, uint32_t multA, SegQ qb, uint32_t Gb, uint32_t Bb, uint32_t multB,
+                                 uint32_t* totals, uint32_t slotA, uint32_t slotB) {
+    const SegQ q = blockIdx.x == 0 ? qa : qb;
+    const uint32_t G = blockIdx.x == 0 ? Ga : Gb, B = blockIdx.x == 0 ? Ba : Bb, mult = blockIdx.x == 0 ? multA : multB;
+    const uint32_t l = threadIdx.x;
+    const uint32_t c = q.ctl[SEGQ_COUNT + l * QSTRIDE];
+    uint32_t x = c;   // inclusive scan over the 64 segments
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (l >= d) x += y;
+    }
+    q.ctl[SEGQ_PREFIX + l] = x - c;
+    if (l == 63u) {
+        q.ctl[SEGQ_PREFIX + QSEG] = x;
+        totals[blockIdx.x == 0 ? slotA : slotB] = x;
+    }
+    q.ctl[SEGQ_START + l] = segq_first_block(l, G) * B * mult;
+    q.ctl[SEGQ_COUNT + l * QSTRIDE] = 0u;
+    q.ctl[SEGQ_CURSOR + l * QSTRIDE] = 0u;
+}
+__global__ void segq_identity_kernel(SegQ q, uint32_t n) {
+    const uint32_t l = threadIdx.x;
+    const uint32_t lo = (uint32_t)(((unsigned long long)l * n) / QSEG);
+    q.ctl[SEGQ_PREFIX + l] = lo;
+    q.ctl[SEGQ_START + l] = lo;
+    if (l == 63u) q.ctl[SEGQ_PREFIX + QSEG] = n;
+    q.ctl[SEGQ_COUNT + l * QSTRIDE] = 0u;
+    q.ctl[SEGQ_CURSOR + l * QSTRIDE] = 0u;
+}
+void launch_segq_scan(const SegQ& q, uint32_t producerBlocks, uint32_t blockThreads, uint32_t mult, uint32_t* totals,
+                      uint32_t totalsSlot, hipStream_t stream) {
+    hipLaunchKernelGGL(segq_scan_kernel, dim3(1), dim3(64), 0, stream, q, producerBlocks ? producerBlocks : 1u, blockThreads, mult, q, 1u,
+                       blockThreads, mult, totals, totalsSlot, totalsSlot);
+}
+void launch_segq_scan2(const SegQ& qa, uint32_t Ga, uint32_t multA, const SegQ& qb, uint32_t Gb, uint32_t multB, uint32_t blockThreads,
+                       uint32_t* totals, hipStream_t stream) {
+    hipLaunchKernelGGL(segq_scan_kernel, dim3(2), dim3(64), 0, stream, qa, Ga ? Ga : 1u, blockThreads, multA, qb, Gb ? Gb : 1u, blockThreads,
+                       multB, totals, 0u, 1u);
+}
+void launch_segq_identity(const SegQ& q, uint32_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(segq_identity_kernel, dim3(1), dim3(64), 0, stream, q, n);
+}
+
+// Persistent extend kernel. Lanes pull rays from a segmented queue: a wave refills its idle lanes (one atomic for
+// the group, slots handed out by a ballot prefix) whenever at least REFILL_MIN lanes are idle or nothing is left to
+// do, so a wave keeps most lanes busy although rays finish at very different times. Between refills the wave runs
+// "while-while": descend inner nodes until every active lane holds a leaf (or is done), then test leaves together.
+// Every wave leaves the loop once the queue is drained and all of its lanes have finished.
+#ifndef REFILL_MIN
+#define REFILL_MIN 16
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(TRAV_BLOCK) void extend_kernel(DevScene sc, const float4* __restrict__ rays, uint32_t n,
-                                                            int hitSide, int withLights, float4* __restrict__ hits,
-                                                            const uint32_t* __restrict__ queue, uint32_t* workCounter,
-                                                            uint2* spill, unsigned long long* counters) {
+__global__ __launch_bounds__(TRAV_BLOCK) void extend_kernel(DevScene sc, const float4* __restrict__ rays, SegQ q,
+                                                            const uint32_t* __restrict__ items, int hitSide, int withLights,
+                                                            float4* __restrict__ hits, uint2* spill, unsigned long long* counters,
+                                                            uint32_t chunk) {
     __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
-    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
     TravStack st{&lds_stack[threadIdx.x], spill + gtid, gridDim.x * blockDim.x};
     uint32_t nodeCount = 0, triCount = 0, rayCount = 0;
+    TravState s;
+    s.cur = RTX_TRAV_DONE;
+    s.sp = 0;
+    bool active = false;      // this lane holds a ray
+    bool exhausted = false;   // the queue is drained (wave-uniform)
+    SegWalk walk;
+    segq_walk_init(q, walk, gtid >> 6, chunk);
+    uint32_t rayIndex = 0;
     for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(workCounter, 64u);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= n) break;
-        const uint32_t qi = base + lane;
-        if (qi < n) {
-            const uint32_t i = queue ? queue[qi] : qi;   // ray queue indirection (path slots) or identity
-            const float4 a = rays[2 * (size_t)i], b = rays[2 * (size_t)i + 1];
-            RayT r{a.x, a.y, a.z, b.x, b.y, b.z, a.w};
-            HitT h = traverse_closest<COUNT>(sc, r, hitSide, st, &nodeCount, &triCount);
-            if (withLights) intersect_lights(sc, r, h);
-            hits[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.slot));
+        // ---- refill idle lanes ----
+        const unsigned long long idle = __ballot(!active);
+        const uint32_t nIdle = (uint32_t)__popcll(idle);
+        if (!exhausted && (nIdle >= REFILL_MIN || nIdle == 64u)) {
+            uint32_t first = 0;
+            const uint32_t got = segq_take(q, walk, nIdle, first);
+            if (got == 0u) exhausted = true;
+            if (!active) {
+                const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (prefix < got) {
+                    rayIndex = items ? items[first + prefix] : first + prefix;   // path slots or identity
+                    const float4 a = rays[2 * (size_t)rayIndex], b = rays[2 * (size_t)rayIndex + 1];
+                    trav_init(s, sc, RayT{a.x, a.y, a.z, b.x, b.y, b.z, a.w});
+                    active = true;
+                }
+            }
+        }
+        if (__ballot(active) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- while-while traversal round ----
+        while (active && trav_is_inner(s.cur)) {
+            if (COUNT) nodeCount++;
+            trav_inner_step(s, sc, st);
+        }
+        if (active && s.cur != RTX_TRAV_DONE) {
+            const uint32_t nt = trav_leaf_step(s, sc, st, hitSide);
+            if (COUNT) triCount += nt;
+        }
+        if (active && s.cur == RTX_TRAV_DONE) {
+            if (withLights) intersect_lights(sc, s.r, s.best);
+            hits[rayIndex] = make_float4(s.best.t, s.best.u, s.best.v, __int_as_float(s.best.slot));
             if (COUNT) rayCount++;
+            active = false;
         }
     }
     if (COUNT) {
@@ -39,18 +120,24 @@ __global__ __launch_bounds__(TRAV_BLOCK) void extend_kernel(DevScene sc, const f
     }
 }
 
-void launch_extend(const DevScene& sc, const LaunchCfg& cfg, const float4* rays, uint32_t n, int hitSide, int withLights,
-                   float4* hits, const uint32_t* queue) {
+void launch_extend_queue(const DevScene& sc, const LaunchCfg& cfg, const float4* rays, const SegQ& q, const uint32_t* items,
+                         uint32_t n, int hitSide, int withLights, float4* hits) {
     if (n == 0) return;
-    (void)hipMemsetAsync(cfg.workCounter, 0, sizeof(uint32_t), cfg.stream);
     const uint32_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
     const uint32_t grid = need < (uint32_t)cfg.gridBlocks ? need : (uint32_t)cfg.gridBlocks;
+    const uint32_t chunk = segq_chunk(n, grid * (TRAV_BLOCK / 64));
     if (cfg.counting)
-        hipLaunchKernelGGL(extend_kernel<true>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, rays, n, hitSide,
-                           withLights, hits, queue, cfg.workCounter, cfg.spill, cfg.counters);
+        hipLaunchKernelGGL(extend_kernel<true>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, rays, q, items, hitSide, withLights,
+                           hits, cfg.spill, cfg.counters, chunk);
     else
-        hipLaunchKernelGGL(extend_kernel<false>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, rays, n, hitSide,
-                           withLights, hits, queue, cfg.workCounter, cfg.spill, cfg.counters);
+        hipLaunchKernelGGL(extend_kernel<false>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, rays, q, items, hitSide, withLights,
+                           hits, cfg.spill, cfg.counters, chunk);
+}
+void launch_extend(const DevScene& sc, const LaunchCfg& cfg, const float4* rays, uint32_t n, int hitSide, int withLights,
+                   float4* hits) {
+    if (n == 0) return;
+    launch_segq_identity(cfg.identQ, n, cfg.stream);
+    launch_extend_queue(sc, cfg, rays, cfg.identQ, nullptr, n, hitSide, withLights, hits);
 }
 
 // CameraAdapter.h:7-27

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "layout.h"
+#include "segqueue.h"
 
 #define PF_LAST_DELTA 1u
 #define PF_INSIDE_MEDIUM 2u
@@ -41,10 +42,13 @@ struct PathPool {
     float4* normal;         // first-hit geometric normal
     float2* samplePos;      // film position of the sample
     // queues
+    // queues (segmented, segqueue.h): items of the two path queues, entries of the shadow queue
     uint32_t* queueA;
     uint32_t* queueB;
     float4* shadowQ;        // 2 per entry: {offset origin xyz, maxDist}, {unit dir xyz, bits(slot*8+light)}
-    uint32_t* counters;     // [0] next-queue count, [1] shadow-queue count, [2..] scratch
+    SegQ qA, qB, qS;        // control words of queueA / queueB / shadowQ
+    uint32_t* totals;       // [0] entries of the queue shade appended to, [1] entries of the shadow queue
+    uint32_t* counters;     // scratch counters ([8] adaptive refinement list)
     // per pixel (full frame)
     int* pixels;            // pixel list of the current round (padded to 64 with -1)
     int* pixelsNext;

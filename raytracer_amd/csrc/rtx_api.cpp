@@ -251,6 +251,12 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     (void)hipMemset(p, 0, 256);
     s->cfg.workCounter = (uint32_t*)p;
     s->cfg.counters = (unsigned long long*)((char*)p + 64);
+    if (hipMalloc(&p, SEGQ_WORDS * sizeof(uint32_t)) != hipSuccess) {
+        rtx_scene_destroy(s);
+        return rtx_fail(RTX_ERR_HIP, "queue control allocation failed");
+    }
+    s->owned.push_back(p);
+    s->cfg.identQ.ctl = (uint32_t*)p;
 #undef CHECK_RC
     RTX_HIP(hipDeviceSynchronize());
     *out = s;

@@ -78,9 +78,15 @@ static int ensure_pool(rtx_scene* s, uint32_t slots, size_t framePixels, size_t 
     PA(albedo, slots);
     PA(normal, slots);
     PA(samplePos, slots);
-    PA(queueA, slots);
-    PA(queueB, slots);
-    PA(shadowQ, 2 * (size_t)nL * slots);
+    // queue regions are laid out per producer block of 256 threads: round the capacity up to whole blocks
+    const size_t qcap = (((size_t)slots + 255) / 256) * 256;
+    PA(queueA, qcap);
+    PA(queueB, qcap);
+    PA(shadowQ, 2 * (size_t)nL * qcap);
+    PA(qA.ctl, SEGQ_WORDS);
+    PA(qB.ctl, SEGQ_WORDS);
+    PA(qS.ctl, SEGQ_WORDS);
+    PA(totals, 16);
     PA(counters, 64);
     PA(pixels, ph->framePixels + 64);
     PA(pixelsNext, ph->framePixels + 64);
@@ -204,6 +210,10 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     // slot * 8 + light must fit 32 bits (shadow queue entries)
     while (S > 1 && (size_t)nPix * S > 0x1FFFFFFFull) --S;
     if ((size_t)nPix * S > 0x1FFFFFFFull) return rtx_fail(RTX_ERR_TOO_LARGE, "more than 2^29 path slots per pass");
+    // shadow queue entries are indexed with 32 bits
+    while (S > 1 && ((size_t)nPix * S + 256) * (size_t)std::max(1, s->dev.n_lights) > 0xFFFFFFFFull) --S;
+    if (((size_t)nPix * S + 256) * (size_t)std::max(1, s->dev.n_lights) > 0xFFFFFFFFull)
+        return rtx_fail(RTX_ERR_TOO_LARGE, "more than 2^32 shadow segments per pass");
     if ((rc = ensure_pool(s, nPix * (uint32_t)S, (size_t)W * H, nPix, usePhotons)) != RTX_OK) return rc;
     PathPoolHost* ph = reinterpret_cast<PathPoolHost*>(s->pool);
     PathPool& pool = ph->dev;
@@ -220,6 +230,11 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     launch_stats_clear(pool, (uint32_t)((size_t)W * H), st);
     RTX_HIP(hipMemsetAsync(pool.rayCounters, 0, 8 * sizeof(unsigned long long), st));
     if (s->cfg.counting) RTX_HIP(hipMemsetAsync(s->cfg.counters, 0, 3 * sizeof(unsigned long long), st));
+    // queue counters are left at zero by every scan; a cancelled or failed call may have left some behind
+    RTX_HIP(hipMemsetAsync(pool.qA.ctl, 0, SEGQ_WORDS * sizeof(uint32_t), st));
+    RTX_HIP(hipMemsetAsync(pool.qB.ctl, 0, SEGQ_WORDS * sizeof(uint32_t), st));
+    RTX_HIP(hipMemsetAsync(pool.qS.ctl, 0, SEGQ_WORDS * sizeof(uint32_t), st));
+    const uint32_t shadowMult = (uint32_t)std::max(1, s->dev.n_lights);
 
     s->cancel.store(0);
     PassTimers tm{ph};
@@ -234,34 +249,36 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
             const int Sp = std::min(S, target - done);
             const int sBase = roundBase + done;
             // ---- one wavefront pass ----
-            RTX_HIP(hipMemsetAsync(pool.counters, 0, 8 * sizeof(uint32_t), st));
             uint32_t* qin = pool.queueA;
             uint32_t* qout = pool.queueB;
-            launch_raygen(dc, pool, curPixels, nPix, Sp, sBase, stride, qin, pool.counters, st);
-            uint32_t n = (uint32_t)(curValid * (size_t)Sp);
+            SegQ sqIn = pool.qA, sqOut = pool.qB;
+            const uint32_t gridGen = launch_raygen(dc, pool, curPixels, nPix, Sp, sBase, stride, sqIn, qin, st);
+            launch_segq_scan(sqIn, gridGen, 256, 1, pool.totals, 2, st);
+            uint32_t n = (uint32_t)(curValid * (size_t)Sp);   // = totals[2]: every valid pixel generates Sp paths
             out.paths += n;
             for (int bounce = 0; bounce < rp->max_bounces && n > 0 && !s->cancel.load(std::memory_order_relaxed); ++bounce) {
                 if (bounce == 0) out.rays_primary += n;
                 else out.rays_bounce += n;
                 tm.begin(0, st);
-                launch_extend(s->dev, s->cfg, pool.rays, n, RTX_HIT_FRONT_AND_BACK, 1, pool.hits, qin);
+                launch_extend_queue(s->dev, s->cfg, pool.rays, sqIn, qin, n, RTX_HIT_FRONT_AND_BACK, 1, pool.hits);
                 tm.end(st);
                 out.extend_launches++;
-                RTX_HIP(hipMemsetAsync(pool.counters, 0, 2 * sizeof(uint32_t), st));
                 tm.begin(2, st);
-                launch_shade(s->dev, dc, pool, pm, qin, n, bounce, rp->max_bounces, rp->seed, sBase, Sp, curPixels, qout,
-                             pool.counters, st);
+                const uint32_t gridShade = launch_shade(s->dev, dc, pool, pm, sqIn, qin, n, bounce, rp->max_bounces, rp->seed, sBase, Sp,
+                                                        curPixels, sqOut, qout, pool.qS, st);
                 tm.end(st);
+                launch_segq_scan2(sqOut, gridShade, 1, pool.qS, gridShade, shadowMult, 256, pool.totals, st);
                 uint32_t cnt[2] = {0, 0};
-                RTX_HIP(hipMemcpyAsync(cnt, pool.counters, sizeof(cnt), hipMemcpyDeviceToHost, st));
+                RTX_HIP(hipMemcpyAsync(cnt, pool.totals, sizeof(cnt), hipMemcpyDeviceToHost, st));
                 RTX_HIP(hipStreamSynchronize(st));
                 if (cnt[1]) {
                     tm.begin(1, st);
-                    launch_shadow(s->dev, s->cfg, pool, cnt[1], bounce <= 8 ? 1 : 0);   // useTransmittance (RayCaster.cpp:454)
+                    launch_shadow(s->dev, s->cfg, pool, pool.qS, cnt[1], bounce <= 8 ? 1 : 0);   // useTransmittance (RayCaster.cpp:454)
                     tm.end(st);
                 }
-                launch_resolve(pool, qin, n, s->dev.n_lights, usePhotons ? 1 : 0, st);
+                launch_resolve(pool, sqIn, qin, n, s->dev.n_lights, usePhotons ? 1 : 0, st);
                 std::swap(qin, qout);
+                std::swap(sqIn, sqOut);
                 n = cnt[0];
                 if (tm.spans.size() > 2048) {
                     RTX_HIP(hipStreamSynchronize(st));

@@ -1,0 +1,141 @@
+// Segmented work queues between the wavefront kernels.
+//
+// A queue append needs one returning atomic per wave, and atomics on ONE address are served at about 11 ns each on
+// MI355X (tools/micro/atomic_rate.hip): with ~10^7 waves per frame a single queue counter alone would cost more than the
+// shading it feeds. A SegQ therefore has QSEG independent segments, each with its own counter in its own 128-byte
+// line. A producer block appends to the segment its block index selects; the segment's region of the item array
+// starts where the first block of that segment would write if nothing were dropped, so regions never overlap and
+// every segment is dense. segq_scan_kernel turns the counters into an exclusive prefix (and the total, for the host),
+// and consumers either map a flat index through the prefix (one thread per item) or drain the segments through
+// per-segment cursors (persistent kernels).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define QSEG 64u          // segments per queue (= lanes of a wave: one lane scans / inspects one segment)
+#define QSTRIDE 32u       // uint32 stride between per-segment counters: one 128-byte line each
+#define SEGQ_COUNT 0u                       // [QSEG * QSTRIDE] appended entries per segment (producers, atomics)
+#define SEGQ_CURSOR (QSEG * QSTRIDE)        // [QSEG * QSTRIDE] consumed entries per segment (persistent consumers)
+#define SEGQ_PREFIX (2u * QSEG * QSTRIDE)   // [QSEG + 1] exclusive prefix of the counts; [QSEG] = total
+#define SEGQ_START (SEGQ_PREFIX + QSEG + 16u)   // [QSEG] first item index of each segment's region
+#define SEGQ_WORDS (SEGQ_START + QSEG + 16u)
+
+struct SegQ {
+    uint32_t* ctl;        // SEGQ_WORDS control words (layout above)
+};
+
+// Segment of producer block b in a grid of G blocks, and the first block of segment s.
+__host__ __device__ inline uint32_t segq_segment_of_block(uint32_t b, uint32_t G) {
+    return (uint32_t)(((unsigned long long)b * QSEG) / G);
+}
+__host__ __device__ inline uint32_t segq_first_block(uint32_t s, uint32_t G) {
+    return (uint32_t)(((unsigned long long)s * G + QSEG - 1u) / QSEG);
+}
+
+#ifdef __HIPCC__
+// Producer side: every lane of the wave calls this (pred = lane has an entry); returns the item index to write.
+// mult = entries a producer thread can append at most (region size per block = blockDim.x * mult).
+__device__ __forceinline__ uint32_t segq_append(const SegQ& q, bool pred, uint32_t mult) {
+    const uint32_t seg = segq_segment_of_block(blockIdx.x, gridDim.x);
+    const unsigned long long mask = __ballot(pred);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total = (uint32_t)__popcll(mask);
+    uint32_t base = 0;
+    if (total) {
+        const int leader = __ffsll((long long)mask) - 1;
+        if ((int)lane == leader) base = atomicAdd(&q.ctl[SEGQ_COUNT + seg * QSTRIDE], total);
+        base = __shfl(base, leader);
+    }
+    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    return segq_first_block(seg, gridDim.x) * blockDim.x * mult + base + prefix;
+}
+
+// Flat consumer: item index of entry i (i < total). tab = LDS copy of prefix[QSEG+1] followed by start[QSEG],
+// filled by segq_load_table (all threads of the block call it, then __syncthreads()).
+#define SEGQ_TABLE_WORDS (2u * QSEG + 1u)
+__device__ __forceinline__ void segq_load_table(const SegQ& q, uint32_t* tab) {
+    for (uint32_t k = threadIdx.x; k < SEGQ_TABLE_WORDS; k += blockDim.x)
+        tab[k] = k <= QSEG ? q.ctl[SEGQ_PREFIX + k] : q.ctl[SEGQ_START + (k - QSEG - 1u)];
+}
+__device__ __forceinline__ uint32_t segq_item_index(const uint32_t* tab, uint32_t i) {
+    uint32_t s = 0;
+#pragma unroll
+    for (uint32_t step = QSEG / 2u; step > 0u; step >>= 1)
+        if (tab[s + step] <= i) s += step;   // largest s with prefix[s] <= i
+    return tab[QSEG + 1u + s] + (i - tab[s]);
+}
+
+// First segment of a persistent consumer wave. Waves start in SEGQ_GROUPS groups spread over the queue and walk
+// forward from there: enough distinct counters to keep the atomics off one address, few enough active regions that
+// the waves running at the same time work on neighbouring rays (which share BVH nodes in L2).
+#ifndef SEGQ_GROUPS
+#define SEGQ_GROUPS 16u
+#endif
+__device__ __forceinline__ uint32_t segq_home(uint32_t wave) { return (wave % SEGQ_GROUPS) * (QSEG / SEGQ_GROUPS); }
+
+// Persistent consumer. All fields are wave-uniform. A wave reserves `chunk` consecutive entries of its current
+// segment with one atomic and hands them to its lanes over several refills, so most refills cost no atomic round
+// trip (during which the wave's busy lanes would stall too).
+struct SegWalk {
+    uint32_t seg;              // current segment
+    uint32_t cnt, start;       // its entry count and first item index
+    uint32_t resBase, resEnd;  // reserved, not yet handed out entries [resBase, resEnd) of the segment
+    uint32_t chunk;            // entries reserved per atomic (multiple of 64)
+};
+__device__ __forceinline__ void segq_walk_load(const SegQ& q, SegWalk& w) {
+    w.cnt = __builtin_amdgcn_readfirstlane(q.ctl[SEGQ_PREFIX + w.seg + 1u] - q.ctl[SEGQ_PREFIX + w.seg]);
+    w.start = __builtin_amdgcn_readfirstlane(q.ctl[SEGQ_START + w.seg]);
+    w.resBase = w.resEnd = 0u;
+}
+__device__ __forceinline__ void segq_walk_init(const SegQ& q, SegWalk& w, uint32_t wave, uint32_t chunk) {
+    w.seg = segq_home(wave);
+    w.chunk = chunk;
+    segq_walk_load(q, w);
+}
+// The wave asks for `want` <= 64 entries. Returns the number granted (0 = the queue is drained: every segment's cursor
+// has passed its count) and the item index of the first one in `first`; granted entries are consecutive. Fewer than
+// `want` may be granted when a reservation runs out; the caller asks again at its next refill.
+__device__ __forceinline__ uint32_t segq_take(const SegQ& q, SegWalk& w, uint32_t want, uint32_t& first) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (;;) {
+        if (w.resBase < w.resEnd) {
+            const uint32_t g = min(want, w.resEnd - w.resBase);
+            first = w.start + w.resBase;
+            w.resBase += g;
+            return g;
+        }
+        if (w.cnt) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&q.ctl[SEGQ_CURSOR + w.seg * QSTRIDE], w.chunk);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base < w.cnt) {
+                w.resBase = base;
+                w.resEnd = min(w.cnt, base + w.chunk);
+                continue;
+            }
+        }
+        // this segment is drained: lane l looks at segment l, continue with the next one that still has entries
+        const uint32_t c = q.ctl[SEGQ_PREFIX + lane + 1u] - q.ctl[SEGQ_PREFIX + lane];
+        const uint32_t cur = __atomic_load_n(&q.ctl[SEGQ_CURSOR + lane * QSTRIDE], __ATOMIC_RELAXED);
+        const unsigned long long open = __ballot(cur < c);
+        if (open == 0ull) return 0u;
+        const unsigned long long above = w.seg < 63u ? (open >> (w.seg + 1u)) << (w.seg + 1u) : 0ull;
+        w.seg = (uint32_t)(__ffsll((long long)(above ? above : open)) - 1);
+        segq_walk_load(q, w);
+    }
+}
+#endif
+
+// Host-callable wrappers (kernels_trace.hip)
+// counts -> prefix/start/total for a queue produced by a grid of G blocks of B threads appending <= mult entries per
+// thread; zeroes the counters and cursors; totals[slot] = number of entries.
+void launch_segq_scan(const SegQ& q, uint32_t producerBlocks, uint32_t blockThreads, uint32_t mult, uint32_t* totals,
+                      uint32_t totalsSlot, hipStream_t stream);
+// identity queue over [0, n): segment s covers [s*n/QSEG, (s+1)*n/QSEG)
+void launch_segq_identity(const SegQ& q, uint32_t n, hipStream_t stream);
+// entries a persistent consumer wave reserves per atomic, for n entries drained by `waves` waves
+inline uint32_t segq_chunk(uint32_t n, uint32_t waves) {
+    unsigned long long c = (unsigned long long)n / ((unsigned long long)(waves ? waves : 1u) * 8ull);
+    c = (c / 64ull) * 64ull;
+    return (uint32_t)(c < 64ull ? 64ull : (c > 1024ull ? 1024ull : c));
+}

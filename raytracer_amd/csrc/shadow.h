@@ -24,48 +24,63 @@ __device__ __forceinline__ void triangle_gn(const DevScene& sc, const RayT& r, i
     obj = (int)(sc.attrs[slot].obj_mtl & 0xFFFFu);
 }
 
+// End of one hop of the chain (RayCaster.cpp:205-276): h is the closest hit of the segment (o, d, maxDist), lights
+// included. Returns true when the chain ends (value in `result`), false when the next hop starts from the updated
+// (o, maxDist) with the updated running visibility.
+__device__ __forceinline__ bool shadow_hop_end(const DevScene& sc, f3& o, f3 d, float& maxDist, const HitT& h, bool useTransmittance,
+                                               int& hop, float& visibility, float& result) {
+    result = visibility;
+    if (h.slot == -1) return true;   // nothing blocking
+    if (h.slot <= -2) return true;   // hit the light itself
+    const f3 hp = o + d * h.t;
+    const float dist = len3(hp - o);
+    if (dist >= maxDist - 1e-4f) return true;
+    result = 0.0f;
+    if (!useTransmittance) return true;    // VisibleSimple :189
+    f3 GN;
+    bool front;
+    int obj;
+    const RayT r{o.x, o.y, o.z, d.x, d.y, d.z, maxDist};
+    triangle_gn(sc, r, h.slot, GN, front, obj);
+    const int mi = sc.objs[obj].material;
+    if (mi < 0) return true;
+    const DevMaterial& m = sc.mtls[mi];
+    const float transFactor = fmaxf(m.kt[0], fmaxf(m.kt[1], m.kt[2]));
+    if (transFactor <= 0.0f) return true;
+    const float ior = m.ior;
+    float cosTheta = fabsf(dot3(GN, -d));
+    const float etaI = front ? 1.0f : ior;
+    const float etaT = front ? ior : 1.0f;
+    cosTheta = fminf(fmaxf(cosTheta, 0.0f), 1.0f);
+    float r0 = (etaI - etaT) / (etaI + etaT);
+    r0 = r0 * r0;
+    const float F = r0 + (1.0f - r0) * powf(1.0f - cosTheta, 5.0f);
+    const float transmit = fmaxf(0.0f, fminf(1.0f, (1.0f - F) * transFactor));
+    visibility *= fmaxf(0.0f, fminf(1.0f, transmit));
+    if (visibility <= 1e-4f) return true;
+    o = offset_point(hp, GN, d);
+    maxDist -= dist;
+    if (maxDist <= 1e-4f) {
+        result = visibility;
+        return true;
+    }
+    ++hop;
+    return hop >= 8;   // kMaxHops with transmittance: the chain gives up with 0
+}
+
 // o = OffsetPoint(origin, normal, dir), d = SafeNormalize(dir) already applied (RayCaster.cpp:199)
 template <bool COUNT>
 __device__ __forceinline__ float visible_chain_from(const DevScene& sc, f3 o, f3 d, float maxDist, bool useTransmittance,
                                                     TravStack st, uint32_t* hops, uint32_t* nodeCount, uint32_t* triCount) {
-    const int kMaxHops = useTransmittance ? 8 : 1;
-    float visibility = 1.0f;
-    for (int hop = 0; hop < kMaxHops; ++hop) {
-        RayT r{o.x, o.y, o.z, d.x, d.y, d.z, maxDist};
+    float visibility = 1.0f, result = 1.0f;
+    int hop = 0;
+    for (;;) {
+        const RayT r{o.x, o.y, o.z, d.x, d.y, d.z, maxDist};
         (*hops)++;
         HitT h = traverse_closest<COUNT>(sc, r, RTX_HIT_FRONT_AND_BACK, st, nodeCount, triCount);
         intersect_lights(sc, r, h);
-        if (h.slot == -1) return visibility;   // nothing blocking
-        if (h.slot <= -2) return visibility;   // hit the light itself
-        const f3 hp = o + d * h.t;
-        const float dist = len3(hp - o);
-        if (dist >= maxDist - 1e-4f) return visibility;
-        if (!useTransmittance) return 0.0f;    // VisibleSimple :189
-        f3 GN;
-        bool front;
-        int obj;
-        triangle_gn(sc, r, h.slot, GN, front, obj);
-        const int mi = sc.objs[obj].material;
-        if (mi < 0) return 0.0f;
-        const DevMaterial& m = sc.mtls[mi];
-        const float transFactor = fmaxf(m.kt[0], fmaxf(m.kt[1], m.kt[2]));
-        if (transFactor <= 0.0f) return 0.0f;
-        const float ior = m.ior;
-        float cosTheta = fabsf(dot3(GN, -d));
-        const float etaI = front ? 1.0f : ior;
-        const float etaT = front ? ior : 1.0f;
-        cosTheta = fminf(fmaxf(cosTheta, 0.0f), 1.0f);
-        float r0 = (etaI - etaT) / (etaI + etaT);
-        r0 = r0 * r0;
-        const float F = r0 + (1.0f - r0) * powf(1.0f - cosTheta, 5.0f);
-        const float transmit = fmaxf(0.0f, fminf(1.0f, (1.0f - F) * transFactor));
-        visibility *= fmaxf(0.0f, fminf(1.0f, transmit));
-        if (visibility <= 1e-4f) return 0.0f;
-        o = offset_point(hp, GN, d);
-        maxDist -= dist;
-        if (maxDist <= 1e-4f) return visibility;
+        if (shadow_hop_end(sc, o, d, maxDist, h, useTransmittance, hop, visibility, result)) return result;
     }
-    return useTransmittance ? 0.0f : visibility;
 }
 
 template <bool COUNT>

@@ -97,102 +97,132 @@ __device__ __forceinline__ void test_triangle(const float4 a, const float4 b, co
     bestPrim = prim;
 }
 
-// Closest hit along r within (EPS, r.tmax). best.t starts at r.tmax (HitInfo::z in-out, IntersectNodeAdapter.h:28).
+// ---- traversal as a small state machine -------------------------------------------------------------------
+// cur: RTX_TRAV_DONE, an inner-node index, or a leaf reference. The kernels run it "while-while": all lanes of a
+// wave first descend inner nodes until each holds a leaf (or is done), then all test their leaves together, so
+// the node code and the triangle code each run with as many active lanes as possible.
+#define RTX_TRAV_DONE 0xFFFFFFFFu   // == RTX_EMPTY_CHILD: never a valid child to visit
+
+struct TravState {
+    RayT r;
+    float idx, idy, idz;     // 1 / dir (IEEE: +-inf for axis-parallel rays)
+    HitT best;
+    uint32_t bestPrim;
+    uint32_t cur;
+    int sp;
+};
+
+__device__ __forceinline__ void trav_init(TravState& s, const DevScene& sc, const RayT& r) {
+    s.r = r;
+    s.idx = 1.0f / r.dx;
+    s.idy = 1.0f / r.dy;
+    s.idz = 1.0f / r.dz;
+    s.best.t = r.tmax;      // HitInfo::z in-out upper bound (IntersectNodeAdapter.h:28)
+    s.best.u = 0.0f;
+    s.best.v = 0.0f;
+    s.best.slot = -1;
+    s.bestPrim = 0xFFFFFFFFu;
+    s.cur = sc.root;        // RTX_EMPTY_CHILD for an empty scene == DONE
+    s.sp = 0;
+}
+__device__ __forceinline__ bool trav_is_inner(uint32_t cur) { return (cur & RTX_LEAF_FLAG) == 0u; }
+
+// next subtree that can still hold a closer (or tying) hit
+__device__ __forceinline__ void trav_pop(TravState& s, TravStack& st) {
+    uint32_t next = RTX_TRAV_DONE;
+    while (s.sp > 0) {
+        const uint2 e = st.pop(s.sp);
+        if (__uint_as_float(e.y) <= s.best.t) {
+            next = e.x;
+            break;
+        }
+    }
+    s.cur = next;
+}
+
+// One inner node (64 B = 4 x dwordx4). The slab test runs in the node's quantised frame: with scale = 2^e exact,
+// t = (q - (ro - o)/scale) * (scale/dir) needs one subtract and one multiply per plane (the byte -> float
+// conversions are single v_cvt_f32_ubyteN instructions). NaNs (0 * inf when the origin lies on a slab plane of an
+// axis-parallel ray) are dropped by fminf/fmaxf; the far side is widened by 2 ulp so rounding never culls a box
+// the ray grazes (the reference's scene_box.cpp:8-46 accepts tmin <= tmax inclusively as well).
+__device__ __forceinline__ void trav_inner_step(TravState& s, const DevScene& sc, TravStack& st) {
+    const uint4* nodes4 = reinterpret_cast<const uint4*>(sc.nodes);
+    const uint4 w0 = nodes4[(size_t)s.cur * 4 + 0];  // ox oy oz | ex ey ez n
+    const uint4 w1 = nodes4[(size_t)s.cur * 4 + 1];  // child[4]
+    const uint4 w2 = nodes4[(size_t)s.cur * 4 + 2];  // qlo x[4] y[4] z[4] | qhi x[4]
+    const uint4 w3 = nodes4[(size_t)s.cur * 4 + 3];  // qhi y[4] z[4] | pad
+    const uint32_t ex = w0.w & 0xFFu, ey = (w0.w >> 8) & 0xFFu, ez = (w0.w >> 16) & 0xFFu;
+    // ray origin in quantised units and direction reciprocal per quantised unit (exact power-of-two scalings)
+    const float rox = (s.r.ox - __uint_as_float(w0.x)) * __uint_as_float((254u - ex) << 23);
+    const float roy = (s.r.oy - __uint_as_float(w0.y)) * __uint_as_float((254u - ey) << 23);
+    const float roz = (s.r.oz - __uint_as_float(w0.z)) * __uint_as_float((254u - ez) << 23);
+    const float qdx = s.idx * scale_from_exp(ex), qdy = s.idy * scale_from_exp(ey), qdz = s.idz * scale_from_exp(ez);
+    float ct[4];
+    uint32_t cr[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t sh = 8u * i;
+        const float t0x = ((float)((w2.x >> sh) & 0xFFu) - rox) * qdx, t1x = ((float)((w2.w >> sh) & 0xFFu) - rox) * qdx;
+        const float t0y = ((float)((w2.y >> sh) & 0xFFu) - roy) * qdy, t1y = ((float)((w3.x >> sh) & 0xFFu) - roy) * qdy;
+        const float t0z = ((float)((w2.z >> sh) & 0xFFu) - roz) * qdz, t1z = ((float)((w3.y >> sh) & 0xFFu) - roz) * qdz;
+        const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+        const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), s.best.t));
+        const bool hit = (cr[i] != RTX_EMPTY_CHILD) && (tn <= tf * 1.0000004f);
+        ct[i] = hit ? tn : __builtin_inff();
+    }
+    // sort the four (distance, child) pairs, nearest first (5 compare-exchanges)
+#define RTX_CSWAP(a, b)                                     \
+    {                                                       \
+        const bool s_ = ct[b] < ct[a];                      \
+        const float tt_ = s_ ? ct[b] : ct[a];               \
+        const float tb_ = s_ ? ct[a] : ct[b];               \
+        const uint32_t rt_ = s_ ? cr[b] : cr[a];            \
+        const uint32_t rb_ = s_ ? cr[a] : cr[b];            \
+        ct[a] = tt_; ct[b] = tb_; cr[a] = rt_; cr[b] = rb_; \
+    }
+    RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
+#undef RTX_CSWAP
+    if (ct[3] != __builtin_inff()) st.push(s.sp, cr[3], ct[3]);
+    if (ct[2] != __builtin_inff()) st.push(s.sp, cr[2], ct[2]);
+    if (ct[1] != __builtin_inff()) st.push(s.sp, cr[1], ct[1]);
+    if (ct[0] != __builtin_inff()) s.cur = cr[0];
+    else trav_pop(s, st);
+}
+
+// One leaf: up to 4 consecutive 48-byte records. Returns the number of triangles tested.
+__device__ __forceinline__ uint32_t trav_leaf_step(TravState& s, const DevScene& sc, TravStack& st, int hitSide) {
+    const float4* tris4 = reinterpret_cast<const float4*>(sc.tris);
+    const uint32_t first = (s.cur & 0x7FFFFFFFu) >> 3;
+    const uint32_t cnt = (s.cur & 7u) + 1u;
+    for (uint32_t k = 0; k < cnt; ++k) {
+        const uint32_t slot = first + k;
+        const float4 a = tris4[(size_t)slot * 3 + 0];
+        const float4 b = tris4[(size_t)slot * 3 + 1];
+        const float4 c = tris4[(size_t)slot * 3 + 2];
+        test_triangle(a, b, c, s.r, hitSide, slot, sc.tris, s.best, s.bestPrim);
+    }
+    trav_pop(s, st);
+    return cnt;
+}
+
+// Closest hit along r within (EPS, r.tmax), run to completion by one lane (shadow chains, photons).
 // counters (optional): [0] += nodes visited, [1] += triangles tested.
 template <bool COUNT>
 __device__ __forceinline__ HitT traverse_closest(const DevScene& sc, const RayT& r, int hitSide, TravStack st,
                                                  uint32_t* nodeCount, uint32_t* triCount) {
-    HitT best;
-    best.t = r.tmax;
-    best.u = 0.0f;
-    best.v = 0.0f;
-    best.slot = -1;
-    uint32_t bestPrim = 0xFFFFFFFFu;
-    if (sc.root == RTX_EMPTY_CHILD) return best;
-
-    const float idx = 1.0f / r.dx, idy = 1.0f / r.dy, idz = 1.0f / r.dz;
-    int sp = 0;
-    uint32_t cur = sc.root;
-    const uint4* nodes4 = reinterpret_cast<const uint4*>(sc.nodes);
-    const float4* tris4 = reinterpret_cast<const float4*>(sc.tris);
-
-    for (;;) {
-        if (!(cur & RTX_LEAF_FLAG)) {
-            // ---- inner node: 64 B = 4 x dwordx4 ----
-            const uint4 w0 = nodes4[(size_t)cur * 4 + 0];  // ox oy oz | ex ey ez n
-            const uint4 w1 = nodes4[(size_t)cur * 4 + 1];  // child[4]
-            const uint4 w2 = nodes4[(size_t)cur * 4 + 2];  // qlo x[4] y[4] z[4] | qhi x[4]
-            const uint4 w3 = nodes4[(size_t)cur * 4 + 3];  // qhi y[4] z[4] | pad
+    TravState s;
+    trav_init(s, sc, r);
+    while (s.cur != RTX_TRAV_DONE) {
+        while (trav_is_inner(s.cur)) {
             if (COUNT) (*nodeCount)++;
-            const float ox = __uint_as_float(w0.x), oy = __uint_as_float(w0.y), oz = __uint_as_float(w0.z);
-            const float sx = scale_from_exp(w0.w & 0xFFu), sy = scale_from_exp((w0.w >> 8) & 0xFFu),
-                        sz = scale_from_exp((w0.w >> 16) & 0xFFu);
-            float ct[4];
-            uint32_t cr[4] = {w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t sh = 8u * i;
-                const float lox = fmaf((float)((w2.x >> sh) & 0xFFu), sx, ox);
-                const float loy = fmaf((float)((w2.y >> sh) & 0xFFu), sy, oy);
-                const float loz = fmaf((float)((w2.z >> sh) & 0xFFu), sz, oz);
-                const float hix = fmaf((float)((w2.w >> sh) & 0xFFu), sx, ox);
-                const float hiy = fmaf((float)((w3.x >> sh) & 0xFFu), sy, oy);
-                const float hiz = fmaf((float)((w3.y >> sh) & 0xFFu), sz, oz);
-                const float t0x = (lox - r.ox) * idx, t1x = (hix - r.ox) * idx;
-                const float t0y = (loy - r.oy) * idy, t1y = (hiy - r.oy) * idy;
-                const float t0z = (loz - r.oz) * idz, t1z = (hiz - r.oz) * idz;
-                // fminf/fmaxf drop NaNs (0 * inf when the origin lies on a slab plane of a parallel axis)
-                const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
-                const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best.t));
-                // conservative: widen the far side by 2 ulp so that rounding never culls a box the ray grazes
-                const bool hit = (cr[i] != RTX_EMPTY_CHILD) && (tn <= tf * 1.0000004f);
-                ct[i] = hit ? tn : __builtin_inff();
-            }
-            // sort the four (distance, child) pairs, nearest first (5 compare-exchanges)
-#define RTX_CSWAP(a, b)                                   \
-    {                                                     \
-        const bool s_ = ct[b] < ct[a];                    \
-        const float tt_ = s_ ? ct[b] : ct[a];             \
-        const float tb_ = s_ ? ct[a] : ct[b];             \
-        const uint32_t rt_ = s_ ? cr[b] : cr[a];          \
-        const uint32_t rb_ = s_ ? cr[a] : cr[b];          \
-        ct[a] = tt_; ct[b] = tb_; cr[a] = rt_; cr[b] = rb_; \
-    }
-            RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
-#undef RTX_CSWAP
-            if (ct[3] != __builtin_inff()) st.push(sp, cr[3], ct[3]);
-            if (ct[2] != __builtin_inff()) st.push(sp, cr[2], ct[2]);
-            if (ct[1] != __builtin_inff()) st.push(sp, cr[1], ct[1]);
-            if (ct[0] != __builtin_inff()) {
-                cur = cr[0];
-                continue;
-            }
-        } else {
-            // ---- leaf: up to 4 consecutive 48-byte records ----
-            const uint32_t first = (cur & 0x7FFFFFFFu) >> 3;
-            const uint32_t cnt = (cur & 7u) + 1u;
-            for (uint32_t k = 0; k < cnt; ++k) {
-                const uint32_t slot = first + k;
-                const float4 a = tris4[(size_t)slot * 3 + 0];
-                const float4 b = tris4[(size_t)slot * 3 + 1];
-                const float4 c = tris4[(size_t)slot * 3 + 2];
-                if (COUNT) (*triCount)++;
-                test_triangle(a, b, c, r, hitSide, slot, sc.tris, best, bestPrim);
-            }
+            trav_inner_step(s, sc, st);
         }
-        // ---- pop the next subtree that can still contain a closer (or tying) hit ----
-        bool found = false;
-        while (sp > 0) {
-            const uint2 e = st.pop(sp);
-            if (__uint_as_float(e.y) <= best.t) {
-                cur = e.x;
-                found = true;
-                break;
-            }
+        if (s.cur != RTX_TRAV_DONE) {
+            const uint32_t n = trav_leaf_step(s, sc, st, hitSide);
+            if (COUNT) (*triCount) += n;
         }
-        if (!found) break;
     }
-    return best;
+    return s.best;
 }
 
 // PointLight::IntersectRay (Shading.cpp:65-86) for the renderable lights, applied after the scene hit as in

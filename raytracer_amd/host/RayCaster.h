@@ -28,6 +28,7 @@ struct SamplingConfig {
     int maxBounces = 64;
     uint64_t seed = 0x9e3779b97f4a7c15ULL;
     int rank = 0, world = 1;          // tile sharding across GPUs (one process per GPU)
+    int samplesPerPass = 0;           // samples per pixel in flight at once; 0 = sized from free HBM
 };
 
 class RayCaster {
@@ -62,6 +63,7 @@ public:
         rp.tile_size = 16;
         rp.rank = sampling.rank;
         rp.world = sampling.world;
+        rp.samples_per_pass = sampling.samplesPerPass;
         rtx_photons* ph = photonMapper ? photonMapper->Handle() : nullptr;
         rp.use_photons = ph ? 1 : 0;
         active = gs.Handle();

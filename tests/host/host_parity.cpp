@@ -254,10 +254,11 @@ int main() {
 
     // Stop() from another thread ends a long render early
     rc.sampling.minSamples = rc.sampling.maxSamples = 1024;
+    rc.sampling.samplesPerPass = 2;   // 512 passes, so the render outlasts the stopper's delay on any GPU
     RenderImage img3;
     img3.Init(cam.imgWidth, cam.imgHeight);
     std::thread stopper([&] {
-        std::this_thread::sleep_for(std::chrono::milliseconds(30));
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
         rc.Stop();
     });
     rc.CastRays(img3);

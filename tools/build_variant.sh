@@ -1,0 +1,21 @@
+#!/bin/bash
+# Builds an experimental variant of librtx_amd.so with extra compile flags, for A/B runs on the GPU box:
+#   tools/build_variant.sh NAME "-DSHADE_WAVES_PER_EU=3"   ->  raytracer_amd/variants/librtx_NAME.so
+# Select it at run time with RTX_AMD_LIB=raytracer_amd/variants/librtx_NAME.so (see raytracer_amd/_ffi.py).
+set -e
+name=$1; shift
+root=$(cd "$(dirname "$0")/.." && pwd)
+src=$root/raytracer_amd/csrc
+out=$root/raytracer_amd/variants
+tmp=$(mktemp -d)
+mkdir -p "$out"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -I$src $*"
+pids=()
+for f in kernels_trace.hip kernels_path.hip kernels_photon.hip rtx_api.cpp rtx_render.cpp rtx_photon.cpp bvh_build.cpp; do
+  /opt/rocm/bin/hipcc $FLAGS -c "$src/$f" -o "$tmp/${f%.*}.o" &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait "$p"; done
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o "$out/librtx_$name.so" "$tmp"/*.o -pthread
+rm -rf "$tmp"
+echo "built $out/librtx_$name.so"
