@@ -375,8 +375,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
 
 // ---- shadow --------------------------------------------------------------------------------------------------
 // Visible() for every queued NEE segment (RayCaster.cpp:465): writes the transmittance next to its contribution.
-// Same structure as the extend kernel (persistent waves, per-lane refill from the segmented queue, while-while
-// traversal); a lane keeps its segment over the hops of the transmittance chain.
+// Same structure as the extend kernel (persistent waves, per-lane refill from the segmented queue, one inner or
+// leaf step per iteration); a lane keeps its segment over the hops of the transmittance chain.
+#ifndef LEAF_WEIGHT
+#define LEAF_WEIGHT 1u
+#endif
 #ifndef SHADOW_REFILL_MIN
 #define SHADOW_REFILL_MIN 16
 #endif
@@ -397,9 +400,27 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene sc, PathPoo
     float maxDist = 0.0f, visibility = 1.0f;
     int hop = 0;
     for (;;) {
+        // hops that reached their end are resolved in batches (see extend_kernel): the chain either ends or starts
+        // its next hop in the same lane
+        const bool fin = active && s.cur == RTX_TRAV_DONE;
+        const unsigned long long finMask = __ballot(fin);
+        const unsigned long long freeMask = finMask | __ballot(!active);
+        if (finMask != 0ull && ((uint32_t)__popcll(freeMask) >= SHADOW_REFILL_MIN || freeMask == ~0ull)) {
+            if (fin) {
+                intersect_lights(sc, s.r, s.best);
+                float T;
+                if (shadow_hop_end(sc, o, d, maxDist, s.best, useTransmittance != 0, hop, visibility, T)) {
+                    pool.nee[(size_t)(code & 7u) * pool.capacity + (code >> 3)].w = T;
+                    active = false;
+                } else {
+                    trav_init(s, sc, RayT{o.x, o.y, o.z, d.x, d.y, d.z, maxDist});
+                    hops++;
+                }
+            }
+        }
         const unsigned long long idle = __ballot(!active);
         const uint32_t nIdle = (uint32_t)__popcll(idle);
-        if (!exhausted && (nIdle >= SHADOW_REFILL_MIN || nIdle == 64u)) {
+        if (!exhausted && nIdle >= SHADOW_REFILL_MIN) {
             uint32_t first = 0;
             const uint32_t got = segq_take(q, walk, nIdle, first);
             if (got == 0u) exhausted = true;
@@ -424,18 +445,14 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene sc, PathPoo
             if (exhausted) break;
             continue;
         }
-        while (active && trav_is_inner(s.cur)) trav_inner_step(s, sc, st);
-        if (active && s.cur != RTX_TRAV_DONE) trav_leaf_step(s, sc, st, RTX_HIT_FRONT_AND_BACK);
-        if (active && s.cur == RTX_TRAV_DONE) {
-            intersect_lights(sc, s.r, s.best);
-            float T;
-            if (shadow_hop_end(sc, o, d, maxDist, s.best, useTransmittance != 0, hop, visibility, T)) {
-                pool.nee[(size_t)(code & 7u) * pool.capacity + (code >> 3)].w = T;
-                active = false;
-            } else {
-                trav_init(s, sc, RayT{o.x, o.y, o.z, d.x, d.y, d.z, maxDist});
-                hops++;
-            }
+        {
+            const bool atInner = active && trav_is_inner(s.cur);
+            const bool atLeaf = active && !atInner && s.cur != RTX_TRAV_DONE;
+            const uint32_t nInner = (uint32_t)__popcll(__ballot(atInner)), nLeaf = (uint32_t)__popcll(__ballot(atLeaf));
+            if (nLeaf * LEAF_WEIGHT >= nInner) {
+                if (atLeaf) trav_leaf_step(s, sc, st, RTX_HIT_FRONT_AND_BACK);
+            } else if (atInner)
+                trav_inner_step(s, sc, st);
         }
     }
     atomicAdd(&pool.rayCounters[0], (unsigned long long)hops);

@@ -52,9 +52,14 @@ void launch_segq_identity(const SegQ& q, uint32_t n, hipStream_t stream) {
 
 // Persistent extend kernel. Lanes pull rays from a segmented queue: a wave refills its idle lanes (one atomic for
 // the group, slots handed out by a ballot prefix) whenever at least REFILL_MIN lanes are idle or nothing is left to
-// do, so a wave keeps most lanes busy although rays finish at very different times. Between refills the wave runs
-// "while-while": descend inner nodes until every active lane holds a leaf (or is done), then test leaves together.
+// do, so a wave keeps most lanes busy although rays finish at very different times. Each iteration runs ONE kind of
+// step, inner node or leaf, for the lanes that are at that kind of node; the other lanes wait for their turn, so
+// neither code path runs for a handful of lanes while the rest of the wave idles.
 // Every wave leaves the loop once the queue is drained and all of its lanes have finished.
+// A wave runs the leaf code when at least 1/LEAF_WEIGHT as many lanes wait at a leaf as want to descend.
+#ifndef LEAF_WEIGHT
+#define LEAF_WEIGHT 1u
+#endif
 #ifndef REFILL_MIN
 #define REFILL_MIN 16
 #endif
@@ -76,10 +81,22 @@ __global__ __launch_bounds__(TRAV_BLOCK) void extend_kernel(DevScene sc, const f
     segq_walk_init(q, walk, gtid >> 6, chunk);
     uint32_t rayIndex = 0;
     for (;;) {
-        // ---- refill idle lanes ----
+        // ---- retire finished rays in batches (a handful of lanes running the epilogue every iteration would cost
+        //      more issue slots than the traversal steps themselves), then refill the idle lanes ----
+        const bool fin = active && s.cur == RTX_TRAV_DONE;
+        const unsigned long long finMask = __ballot(fin);
+        const unsigned long long freeMask = finMask | __ballot(!active);
+        if (finMask != 0ull && ((uint32_t)__popcll(freeMask) >= REFILL_MIN || freeMask == ~0ull)) {
+            if (fin) {
+                if (withLights) intersect_lights(sc, s.r, s.best);
+                hits[rayIndex] = make_float4(s.best.t, s.best.u, s.best.v, __int_as_float(s.best.slot));
+                if (COUNT) rayCount++;
+                active = false;
+            }
+        }
         const unsigned long long idle = __ballot(!active);
         const uint32_t nIdle = (uint32_t)__popcll(idle);
-        if (!exhausted && (nIdle >= REFILL_MIN || nIdle == 64u)) {
+        if (!exhausted && nIdle >= REFILL_MIN) {
             uint32_t first = 0;
             const uint32_t got = segq_take(q, walk, nIdle, first);
             if (got == 0u) exhausted = true;
@@ -97,20 +114,20 @@ __global__ __launch_bounds__(TRAV_BLOCK) void extend_kernel(DevScene sc, const f
             if (exhausted) break;
             continue;
         }
-        // ---- while-while traversal round ----
-        while (active && trav_is_inner(s.cur)) {
-            if (COUNT) nodeCount++;
-            trav_inner_step(s, sc, st);
-        }
-        if (active && s.cur != RTX_TRAV_DONE) {
-            const uint32_t nt = trav_leaf_step(s, sc, st, hitSide);
-            if (COUNT) triCount += nt;
-        }
-        if (active && s.cur == RTX_TRAV_DONE) {
-            if (withLights) intersect_lights(sc, s.r, s.best);
-            hits[rayIndex] = make_float4(s.best.t, s.best.u, s.best.v, __int_as_float(s.best.slot));
-            if (COUNT) rayCount++;
-            active = false;
+        // ---- one traversal step for the larger group of lanes ----
+        {
+            const bool atInner = active && trav_is_inner(s.cur);
+            const bool atLeaf = active && !atInner && s.cur != RTX_TRAV_DONE;
+            const uint32_t nInner = (uint32_t)__popcll(__ballot(atInner)), nLeaf = (uint32_t)__popcll(__ballot(atLeaf));
+            if (nLeaf * LEAF_WEIGHT >= nInner) {
+                if (atLeaf) {
+                    const uint32_t nt = trav_leaf_step(s, sc, st, hitSide);
+                    if (COUNT) triCount += nt;
+                }
+            } else if (atInner) {
+                if (COUNT) nodeCount++;
+                trav_inner_step(s, sc, st);
+            }
         }
     }
     if (COUNT) {
