@@ -149,7 +149,7 @@ __device__ __forceinline__ bool has_map_or_value(const float* c, int tex) {   //
 // One bounce of TracePath (RayCaster.cpp:359-567) for every path in queueIn. Paths that continue are appended to
 // queueOut; NEE shadow segments are appended to the shadow queue; their results are folded in by resolve_kernel.
 #ifndef SHADE_WAVES_PER_EU
-#define SHADE_WAVES_PER_EU 2
+#define SHADE_WAVES_PER_EU 3
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES_PER_EU))) void shade_kernel(DevScene sc, DevCamera cam, PathPool pool, DevPhotonMap pm,
                                                     SegQ qIn, const uint32_t* __restrict__ queueIn, uint32_t n, int bounce,
@@ -537,6 +537,11 @@ __device__ __forceinline__ float filter1d(int type, float radius, float x) {   /
 
 // One lane per pixel of the pass: walks its S samples in sample order (so per-pixel sums and the running z are
 // accumulated in the reference's order) and splats them into the film with float atomics.
+//
+// NEAR3 (tent filter with radius <= 1, the reference's default): every sample of a pixel lies inside that pixel, so
+// it can only reach the 3x3 pixels around it. The lane sums the S samples' weighted contributions for those nine
+// pixels in registers and issues the atomics once at the end: 9 x 5 atomics per pixel and pass instead of per sample.
+template <bool NEAR3>
 __global__ void film_kernel(PathPool pool, rtx_film film, const int* __restrict__ pixels, uint32_t nPix, int S, int W, int H,
                             int filterType, float filterRadius, int resetZ, float4* __restrict__ samplesOut, int sBase,
                             int sppTotal) {
@@ -552,6 +557,15 @@ __global__ void film_kernel(PathPool pool, rtx_film film, const int* __restrict_
     const float radius = filter_radius(filterType, filterRadius);
     int cnt = film.count[pix];
     bool guide = film.albedo ? (film.albedo[4 * (size_t)pix + 3] != 0.0f) : true;
+    const int px = pix % W, py = pix / W;
+    float accR[9], accG[9], accB[9], accW[9], accZ[9];
+    if (NEAR3) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            accR[k] = accG[k] = accB[k] = accW[k] = 0.0f;
+            accZ[k] = RTX_BIG;
+        }
+    }
     for (int s = 0; s < S; ++s) {
         const uint32_t slot = (chunk * (uint32_t)S + (uint32_t)s) * 64u + lane;
         const float4 L4 = pool.L[slot];
@@ -574,28 +588,68 @@ __global__ void film_kernel(PathPool pool, rtx_film film, const int* __restrict_
             }
         }
         const float2 sp = pool.samplePos[slot];
-        const int x0 = max(0, (int)floorf(sp.x - radius));
-        const int x1 = min(W - 1, (int)ceilf(sp.x + radius));
-        const int y0 = max(0, (int)floorf(sp.y - radius));
-        const int y1 = min(H - 1, (int)ceilf(sp.y + radius));
-        for (int yy = y0; yy <= y1; ++yy) {
-            const float wy = filter1d(filterType, radius, (float)yy + 0.5f - sp.y);
-            if (wy <= 0.0f) continue;
-            for (int xx = x0; xx <= x1; ++xx) {
-                const float wx = filter1d(filterType, radius, (float)xx + 0.5f - sp.x);
-                if (wx <= 0.0f) continue;
-                const float w = wx * wy;
-                const size_t idx = (size_t)yy * W + xx;
-                atomicAdd(&film.accum[4 * idx + 0], cr * w);
-                atomicAdd(&film.accum[4 * idx + 1], cg * w);
-                atomicAdd(&film.accum[4 * idx + 2], cb * w);
-                atomicAdd(&film.accum[4 * idx + 3], w);
-                atomicMin(reinterpret_cast<int*>(&film.z[idx]), __float_as_int(bestZ));   // z >= 0: int order == float order
+        if (NEAR3) {
+            float wx[3], wy[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                wx[k] = filter1d(RTX_FILTER_TENT, radius, (float)(px + k - 1) + 0.5f - sp.x);
+                wy[k] = filter1d(RTX_FILTER_TENT, radius, (float)(py + k - 1) + 0.5f - sp.y);
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float w = wx[kx] * wy[ky];
+                    if (wx[kx] > 0.0f && wy[ky] > 0.0f) {
+                        const int k = ky * 3 + kx;
+                        accR[k] += cr * w;
+                        accG[k] += cg * w;
+                        accB[k] += cb * w;
+                        accW[k] += w;
+                        accZ[k] = fminf(accZ[k], bestZ);
+                    }
+                }
+        } else {
+            const int x0 = max(0, (int)floorf(sp.x - radius));
+            const int x1 = min(W - 1, (int)ceilf(sp.x + radius));
+            const int y0 = max(0, (int)floorf(sp.y - radius));
+            const int y1 = min(H - 1, (int)ceilf(sp.y + radius));
+            for (int yy = y0; yy <= y1; ++yy) {
+                const float wy = filter1d(filterType, radius, (float)yy + 0.5f - sp.y);
+                if (wy <= 0.0f) continue;
+                for (int xx = x0; xx <= x1; ++xx) {
+                    const float wx = filter1d(filterType, radius, (float)xx + 0.5f - sp.x);
+                    if (wx <= 0.0f) continue;
+                    const float w = wx * wy;
+                    const size_t idx = (size_t)yy * W + xx;
+                    atomicAdd(&film.accum[4 * idx + 0], cr * w);
+                    atomicAdd(&film.accum[4 * idx + 1], cg * w);
+                    atomicAdd(&film.accum[4 * idx + 2], cb * w);
+                    atomicAdd(&film.accum[4 * idx + 3], w);
+                    atomicMin(reinterpret_cast<int*>(&film.z[idx]), __float_as_int(bestZ));   // z >= 0: int order == float order
+                }
             }
         }
         n += 1;
         s1.x += cr; s1.y += cg; s1.z += cb;
         s2.x += cr * cr; s2.y += cg * cg; s2.z += cb * cb;
+    }
+    if (NEAR3) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int k = ky * 3 + kx;
+                const int xx = px + kx - 1, yy = py + ky - 1;
+                if (accW[k] > 0.0f && xx >= 0 && xx < W && yy >= 0 && yy < H) {
+                    const size_t idx = (size_t)yy * W + xx;
+                    atomicAdd(&film.accum[4 * idx + 0], accR[k]);
+                    atomicAdd(&film.accum[4 * idx + 1], accG[k]);
+                    atomicAdd(&film.accum[4 * idx + 2], accB[k]);
+                    atomicAdd(&film.accum[4 * idx + 3], accW[k]);
+                    atomicMin(reinterpret_cast<int*>(&film.z[idx]), __float_as_int(accZ[k]));
+                }
+            }
     }
     film.count[pix] = cnt;
     s1.w = __int_as_float(n);
@@ -715,8 +769,13 @@ void launch_resolve(const PathPool& pool, const SegQ& qIn, const uint32_t* queue
 void launch_film(const PathPool& pool, const rtx_film& film, const int* pixels, uint32_t nPix, int S, int W, int H, int filterType,
                  float filterRadius, int resetZ, float4* samplesOut, int sBase, int sppTotal, hipStream_t stream) {
     if (!nPix) return;
-    hipLaunchKernelGGL(film_kernel, dim3((nPix + 255) / 256), dim3(256), 0, stream, pool, film, pixels, nPix, S, W, H, filterType,
-                       filterRadius, resetZ, samplesOut, sBase, sppTotal);
+    const bool near3 = filterType == RTX_FILTER_TENT && (filterRadius <= 0.0f || filterRadius <= 1.0f);
+    if (near3)
+        hipLaunchKernelGGL(film_kernel<true>, dim3((nPix + 255) / 256), dim3(256), 0, stream, pool, film, pixels, nPix, S, W, H,
+                           filterType, filterRadius, resetZ, samplesOut, sBase, sppTotal);
+    else
+        hipLaunchKernelGGL(film_kernel<false>, dim3((nPix + 255) / 256), dim3(256), 0, stream, pool, film, pixels, nPix, S, W, H,
+                           filterType, filterRadius, resetZ, samplesOut, sBase, sppTotal);
 }
 void launch_adaptive(const PathPool& pool, const int* pixels, uint32_t nPix, float maxHalf, int sppMax, int* pixelsNext,
                      uint32_t* counter, hipStream_t stream) {

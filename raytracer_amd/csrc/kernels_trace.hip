@@ -119,6 +119,14 @@ __global__ __launch_bounds__(TRAV_BLOCK) void extend_kernel(DevScene sc, const f
             const bool atInner = active && trav_is_inner(s.cur);
             const bool atLeaf = active && !atInner && s.cur != RTX_TRAV_DONE;
             const uint32_t nInner = (uint32_t)__popcll(__ballot(atInner)), nLeaf = (uint32_t)__popcll(__ballot(atLeaf));
+#ifdef TRAV_PROFILE
+            if (COUNT && (threadIdx.x & 63u) == 0u) {   // wave-level step statistics (variant builds only)
+                const bool leafStep = nLeaf * LEAF_WEIGHT >= nInner;
+                atomicAdd(&counters[leafStep ? 5 : 3], 1ull);
+                atomicAdd(&counters[leafStep ? 6 : 4], (unsigned long long)(leafStep ? nLeaf : nInner));
+                atomicAdd(&counters[7], (unsigned long long)__popcll(__ballot(true)));
+            }
+#endif
             if (nLeaf * LEAF_WEIGHT >= nInner) {
                 if (atLeaf) {
                     const uint32_t nt = trav_leaf_step(s, sc, st, hitSide);

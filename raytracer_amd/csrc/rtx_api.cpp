@@ -314,6 +314,15 @@ int rtx_set_counters(rtx_scene* s, int enabled) {
     return RTX_OK;
 }
 
+#ifdef TRAV_PROFILE
+int rtx_debug_trav_profile(rtx_scene* s, uint64_t out[8]) {   // variant builds only (tools/trav_profile.py)
+    RTX_HIP(hipDeviceSynchronize());
+    RTX_HIP(hipMemcpy(out, s->cfg.counters, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    RTX_HIP(hipMemset(s->cfg.counters, 0, 8 * sizeof(uint64_t)));
+    return RTX_OK;
+}
+#endif
+
 int rtx_get_counters(rtx_scene* s, uint64_t out[3]) {
     if (!s) return rtx_fail(RTX_ERR_INVALID, "scene is NULL");
     RTX_HIP(hipDeviceSynchronize());

@@ -32,7 +32,17 @@ def run(tag, rays, k=10):
     nn = rays.shape[0]
     sc.set_counters(True)
     sc.trace_closest_device(rays.data_ptr(), nn, hits.data_ptr(), _ffi.HIT_FRONT_AND_BACK, True, stream)
-    cnt = sc.get_counters(); sc.set_counters(False)
+    if hasattr(sc.lib, "rtx_debug_trav_profile"):   # variant built with -DTRAV_PROFILE
+        prof = (C.c_uint64 * 8)()
+        sc.lib.rtx_debug_trav_profile.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        sc.lib.rtx_debug_trav_profile(sc.h, prof)
+        p = list(prof)
+        print(f"   steps/ray: inner {p[3]*64/p[2]:.1f} (avg lanes {p[4]/max(p[3],1):.1f})  leaf {p[5]*64/p[2]:.1f} (avg lanes {p[6]/max(p[5],1):.1f})"
+              f"  ideal inner {p[0]/p[2]:.1f} leaf-visits/ray ~{p[1]/p[2]/3:.1f}", flush=True)
+        cnt = {"nodes": p[0], "tris": p[1], "rays": p[2]}
+    else:
+        cnt = sc.get_counters()
+    sc.set_counters(False)
     for _ in range(2): sc.trace_closest_device(rays.data_ptr(), nn, hits.data_ptr(), _ffi.HIT_FRONT_AND_BACK, True, stream)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
