@@ -91,7 +91,8 @@ struct Builder {
                 cnt += bc[b];
                 if (cnt == 0 || rightCnt[b + 1] == 0) continue;
                 // leaves hold up to 4 triangles: count cost in units of leaf fetches
-                float cost = acc.area() * (float)((cnt + 3) / 4) + rightArea[b + 1] * (float)((rightCnt[b + 1] + 3) / 4);
+                float cost = acc.area() * (float)((cnt + RTX_MAX_LEAF - 1) / RTX_MAX_LEAF) +
+                             rightArea[b + 1] * (float)((rightCnt[b + 1] + RTX_MAX_LEAF - 1) / RTX_MAX_LEAF);
                 if (cost < bestCost) {
                     bestCost = cost;
                     bestAxis = a;

@@ -15,7 +15,9 @@
 
 #define RTX_LEAF_FLAG 0x80000000u
 #define RTX_EMPTY_CHILD 0xFFFFFFFFu
-#define RTX_MAX_LEAF 4
+#ifndef RTX_MAX_LEAF
+#define RTX_MAX_LEAF 2
+#endif
 
 // traversal stack budget per lane: STACK_LDS entries in LDS, STACK_GLOBAL more in a global spill slab
 #define STACK_LDS 12

@@ -141,10 +141,15 @@ __device__ __forceinline__ void trav_pop(TravState& s, TravStack& st) {
 }
 
 // One inner node (64 B = 4 x dwordx4). The slab test runs in the node's quantised frame: with scale = 2^e exact,
-// t = (q - (ro - o)/scale) * (scale/dir) needs one subtract and one multiply per plane (the byte -> float
-// conversions are single v_cvt_f32_ubyteN instructions). NaNs (0 * inf when the origin lies on a slab plane of an
-// axis-parallel ray) are dropped by fminf/fmaxf; the far side is widened by 2 ulp so rounding never culls a box
-// the ray grazes (the reference's scene_box.cpp:8-46 accepts tmin <= tmax inclusively as well).
+// t = (q - (ro - o)/scale) * (scale/dir), and the near/far planes of an axis go through one packed subtract and one
+// packed multiply (v_pk_add_f32 / v_pk_mul_f32). Which plane is the near one follows from the sign of the direction,
+// so the near/far bytes of all four children are picked with one select per axis before they are converted (byte ->
+// float is a single v_cvt_f32_ubyteN). Axis-parallel rays (1/dir = +-inf) give +-inf on the right side of the
+// comparison; the NaN of 0 * inf (origin exactly on a plane) is dropped by fminf/fmaxf, which only makes the test
+// more conservative. The far side is widened by 2 ulp so rounding never culls a box the ray grazes (the reference's
+// scene_box.cpp:8-46 accepts tmin <= tmax inclusively as well). [An FMA form q*k + c turns axis-parallel rays into
+// inf - inf = NaN on every plane: such rays then visit the whole tree.]
+typedef float rtx_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void trav_inner_step(TravState& s, const DevScene& sc, TravStack& st) {
     const uint4* nodes4 = reinterpret_cast<const uint4*>(sc.nodes);
     const uint4 w0 = nodes4[(size_t)s.cur * 4 + 0];  // ox oy oz | ex ey ez n
@@ -152,21 +157,32 @@ __device__ __forceinline__ void trav_inner_step(TravState& s, const DevScene& sc
     const uint4 w2 = nodes4[(size_t)s.cur * 4 + 2];  // qlo x[4] y[4] z[4] | qhi x[4]
     const uint4 w3 = nodes4[(size_t)s.cur * 4 + 3];  // qhi y[4] z[4] | pad
     const uint32_t ex = w0.w & 0xFFu, ey = (w0.w >> 8) & 0xFFu, ez = (w0.w >> 16) & 0xFFu;
-    // ray origin in quantised units and direction reciprocal per quantised unit (exact power-of-two scalings)
+    // direction reciprocal per quantised unit and ray origin in quantised units (exact power-of-two scalings)
+    const float qdx = s.idx * scale_from_exp(ex), qdy = s.idy * scale_from_exp(ey), qdz = s.idz * scale_from_exp(ez);
     const float rox = (s.r.ox - __uint_as_float(w0.x)) * __uint_as_float((254u - ex) << 23);
     const float roy = (s.r.oy - __uint_as_float(w0.y)) * __uint_as_float((254u - ey) << 23);
     const float roz = (s.r.oz - __uint_as_float(w0.z)) * __uint_as_float((254u - ez) << 23);
-    const float qdx = s.idx * scale_from_exp(ex), qdy = s.idy * scale_from_exp(ey), qdz = s.idz * scale_from_exp(ez);
+    // sign bit of 1/dir (also right for -0 -> -inf): negative direction enters through the high plane
+    const bool negx = (__float_as_uint(s.idx) >> 31) != 0u, negy = (__float_as_uint(s.idy) >> 31) != 0u,
+               negz = (__float_as_uint(s.idz) >> 31) != 0u;
+    const uint32_t nqx = negx ? w2.w : w2.x, fqx = negx ? w2.x : w2.w;
+    const uint32_t nqy = negy ? w3.x : w2.y, fqy = negy ? w2.y : w3.x;
+    const uint32_t nqz = negz ? w3.y : w2.z, fqz = negz ? w2.z : w3.y;
+    const rtx_f2 vdx = {qdx, qdx}, vdy = {qdy, qdy}, vdz = {qdz, qdz};
+    const rtx_f2 vrx = {rox, rox}, vry = {roy, roy}, vrz = {roz, roz};
     float ct[4];
     uint32_t cr[4] = {w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t sh = 8u * i;
-        const float t0x = ((float)((w2.x >> sh) & 0xFFu) - rox) * qdx, t1x = ((float)((w2.w >> sh) & 0xFFu) - rox) * qdx;
-        const float t0y = ((float)((w2.y >> sh) & 0xFFu) - roy) * qdy, t1y = ((float)((w3.x >> sh) & 0xFFu) - roy) * qdy;
-        const float t0z = ((float)((w2.z >> sh) & 0xFFu) - roz) * qdz, t1z = ((float)((w3.y >> sh) & 0xFFu) - roz) * qdz;
-        const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
-        const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), s.best.t));
+        const rtx_f2 qx = {(float)((nqx >> sh) & 0xFFu), (float)((fqx >> sh) & 0xFFu)};
+        const rtx_f2 qy = {(float)((nqy >> sh) & 0xFFu), (float)((fqy >> sh) & 0xFFu)};
+        const rtx_f2 qz = {(float)((nqz >> sh) & 0xFFu), (float)((fqz >> sh) & 0xFFu)};
+        const rtx_f2 tx = (qx - vrx) * vdx;
+        const rtx_f2 ty = (qy - vry) * vdy;
+        const rtx_f2 tz = (qz - vrz) * vdz;
+        const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, 0.0f));
+        const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, s.best.t));
         const bool hit = (cr[i] != RTX_EMPTY_CHILD) && (tn <= tf * 1.0000004f);
         ct[i] = hit ? tn : __builtin_inff();
     }
@@ -182,9 +198,20 @@ __device__ __forceinline__ void trav_inner_step(TravState& s, const DevScene& sc
     }
     RTX_CSWAP(0, 1) RTX_CSWAP(2, 3) RTX_CSWAP(0, 2) RTX_CSWAP(1, 3) RTX_CSWAP(1, 2)
 #undef RTX_CSWAP
-    if (ct[3] != __builtin_inff()) st.push(s.sp, cr[3], ct[3]);
-    if (ct[2] != __builtin_inff()) st.push(s.sp, cr[2], ct[2]);
-    if (ct[1] != __builtin_inff()) st.push(s.sp, cr[1], ct[1]);
+    // far children go on the stack, farthest first. Misses sort to the end (inf), so hits are a prefix of ct[1..3].
+    const int h1 = ct[1] != __builtin_inff(), h2 = ct[2] != __builtin_inff(), h3 = ct[3] != __builtin_inff();
+    if (s.sp + 3 <= STACK_LDS) {
+        // all in LDS: three unconditional writes; a slot written for a miss is overwritten by the next write or
+        // stays above the stack top
+        st.lds[s.sp * TRAV_BLOCK] = make_uint2(cr[3], __float_as_uint(ct[3]));
+        st.lds[(s.sp + h3) * TRAV_BLOCK] = make_uint2(cr[2], __float_as_uint(ct[2]));
+        st.lds[(s.sp + h3 + h2) * TRAV_BLOCK] = make_uint2(cr[1], __float_as_uint(ct[1]));
+        s.sp += h1 + h2 + h3;
+    } else {
+        if (h3) st.push(s.sp, cr[3], ct[3]);
+        if (h2) st.push(s.sp, cr[2], ct[2]);
+        if (h1) st.push(s.sp, cr[1], ct[1]);
+    }
     if (ct[0] != __builtin_inff()) s.cur = cr[0];
     else trav_pop(s, st);
 }

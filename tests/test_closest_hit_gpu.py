@@ -97,3 +97,30 @@ def test_transformed_instances(rtx):
     n_g = g["N"][hit] / np.linalg.norm(g["N"][hit], axis=1, keepdims=True)
     n_o = o["N"][hit] / np.linalg.norm(o["N"][hit], axis=1, keepdims=True)
     assert np.abs(n_g - n_o).max() < 1e-3
+
+
+def test_degenerate_directions(c1):
+    """Axis-parallel rays (1/dir = +-inf) and zero-length directions, as the shade kernel can emit after a degenerate
+    reflection: same hits as the oracle, and the box test must still cull (a slab test that turns inf into NaN makes
+    such rays walk the whole tree)."""
+    sd, cam, gs, osc = c1
+    rng = np.random.default_rng(5)
+    n = 4096
+    rays = random_rays(rng, n, osc.bounds())
+    axes = rng.integers(0, 3, n)
+    signs = rng.choice(np.array([-1.0, 1.0], np.float32), n)
+    d = np.zeros((n, 3), np.float32)
+    d[np.arange(n), axes] = signs
+    d[::2, (axes[::2] + 1) % 3] = np.float32(0.6)          # half of them parallel to one axis only
+    d[1::16] = 0.0                                           # some with no direction at all
+    d[np.arange(n) % 7 == 0] = np.where(d[np.arange(n) % 7 == 0] == 0, np.float32(-0.0), d[np.arange(n) % 7 == 0])
+    rays["d"] = d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30).astype(np.float32)
+    gs.set_counters(True)
+    g = gs.trace_closest(rays, _ffi.HIT_FRONT_AND_BACK)
+    cnt = gs.get_counters()
+    gs.set_counters(False)
+    o = osc.trace_closest(rays, _ffi.HIT_FRONT_AND_BACK)
+    compare_hits(g, o, gs.face_base)
+    nodes = gs.info()["nodes"]
+    assert cnt["rays"] == n
+    assert cnt["nodes"] / n < 0.02 * nodes + 200, f"{cnt['nodes'] / n:.0f} nodes per ray of {nodes}"
