@@ -293,6 +293,15 @@ int rtx_debug_validate_bvh(const rtx_scene_desc* desc, uint64_t out[3]) {
     return RTX_OK;
 }
 
+int rtx_debug_queue_layout(uint32_t producer_blocks, uint32_t block_threads, uint32_t mult, uint32_t start[64],
+                           uint32_t* segment_of_block) {
+    if (!producer_blocks || !block_threads || !mult || !start) return rtx_fail(RTX_ERR_INVALID, "bad argument");
+    for (uint32_t s = 0; s < QSEG; ++s) start[s] = segq_first_block(s, producer_blocks) * block_threads * mult;
+    if (segment_of_block)
+        for (uint32_t b = 0; b < producer_blocks; ++b) segment_of_block[b] = segq_segment_of_block(b, producer_blocks);
+    return RTX_OK;
+}
+
 int rtx_scene_info(const rtx_scene* s, uint64_t counts[6], float bounds[6]) {
     if (!s) return rtx_fail(RTX_ERR_INVALID, "scene is NULL");
     if (counts) {

@@ -141,3 +141,29 @@ def test_tile_sharding_partitions_the_frame(W, H, world):
             if len(v):
                 assert len(np.unique((v // W // 16) * nbx + (v % W) // 16)) == 1
     assert (seen == 1).all()
+
+
+@pytest.mark.parametrize("blocks", [1, 2, 63, 64, 65, 1000, 260000])
+@pytest.mark.parametrize("mult", [1, 3])
+def test_segmented_queue_layout(blocks, mult):
+    """csrc/segqueue.h: a producer block appends to the segment its index selects; segment regions must be disjoint,
+    ordered, inside the queue's capacity and large enough for everything the segment's blocks can append."""
+    import ctypes as C
+    lib = _ffi.load_library()
+    start = (C.c_uint32 * 64)()
+    seg = (C.c_uint32 * blocks)()
+    assert lib.rtx_debug_queue_layout(blocks, 256, mult, start, seg) == 0
+    start = np.array(start[:], np.int64)
+    seg = np.array(seg[:], np.int64)
+    assert (np.diff(seg) >= 0).all() and seg.min() >= 0 and seg.max() <= 63
+    cap = blocks * 256 * mult
+    assert (np.diff(start) >= 0).all() and start[0] == 0 and start[-1] <= cap
+    ends = np.append(start[1:], cap)
+    per_seg = np.bincount(seg, minlength=64) * 256 * mult     # worst case: nothing dropped
+    assert (start + per_seg <= ends).all()
+    # the first block of a segment writes at the segment start
+    first = np.full(64, -1, np.int64)
+    for b in range(blocks - 1, -1, -1):
+        first[seg[b]] = b
+    used = first >= 0
+    assert (start[used] == first[used] * 256 * mult).all()
