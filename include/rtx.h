@@ -41,6 +41,10 @@ extern "C" {
 
 #define RTX_MAX_LIGHTS 8
 
+#define RTX_OBJ_MESH 0             /* TriObj,  objects.cpp:128-266 */
+#define RTX_OBJ_SPHERE 1           /* Sphere,  objects.cpp:21-86   */
+#define RTX_OBJ_PLANE 2            /* Plane,   objects.cpp:89-126  */
+
 #define RTX_MTL_BLINN 0            /* Shading.cpp:715-725 */
 #define RTX_MTL_PHONG 1            /* Shading.cpp:727-737 */
 
@@ -71,6 +75,9 @@ typedef struct {
     float xform[12];               /* object->world 3x4 row-major (accumulated Node transforms; identity for
                                       every object of assets/cerealBar.xml:5-51)             */
     int material;                  /* index into rtx_scene_desc.materials; -1 = none         */
+    int kind;                      /* RTX_OBJ_MESH (arrays above), or an analytic object in object space under
+                                      xform: RTX_OBJ_SPHERE = unit sphere (objects.cpp:21-86), RTX_OBJ_PLANE = the
+                                      square [-1,1]^2 at z = 0 (objects.cpp:89-126); arrays are ignored for those */
 } rtx_mesh_desc;
 
 /* Texture image + TextureMap transform (texture-space matrix applied to uvw before lookup). */

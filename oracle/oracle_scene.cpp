@@ -182,7 +182,72 @@ bool Mesh::trace_bvh(const Ray& ray, Hit& hInfo, int hitSide, int nodeID, uint64
 }
 
 // objects.cpp:245-266
+// objects.cpp:21-86 (unit sphere at the origin of object space)
+bool Mesh::intersect_sphere(const Ray& ray, Hit& hInfo, int hitSide) const {
+    const V3& p = ray.p;
+    const V3& d = ray.dir;
+    const float A = dot(d, d);
+    const float B = 2.0f * dot(p, d);
+    const float C = dot(p, p) - 1.0f;
+    const float disc = B * B - 4 * A * C;
+    if (disc < 0.0f) return false;
+    const float s = std::sqrt(disc);
+    const float inv2A = 0.5f / A;
+    const float t0 = (-B - s) * inv2A;
+    const float t1 = (-B + s) * inv2A;
+    float t = -1.0f;
+    if (t0 > EPS) t = t0;
+    else if (t1 > EPS) t = t1;
+    if (t < 0.0f || t >= hInfo.z) return false;
+    const V3 hp = p + d * t;
+    const V3 GN = normalized(hp);
+    const bool front = dot(d, GN) < 0.0f;
+    if ((hitSide == RTX_HIT_FRONT && !front) || (hitSide == RTX_HIT_BACK && front)) return false;
+    hInfo.z = t;
+    hInfo.p = hp;
+    hInfo.GN = GN;
+    hInfo.N = GN;
+    hInfo.front = front;
+    const V3 n = normalized(hp);
+    const float PIf = 3.14159265358979323846f;
+    const float phi = std::atan2(n.y, n.x);
+    const float theta = std::acos(std::min(1.0f, std::max(-1.0f, n.z)));
+    hInfo.uvw = V3((phi + PIf) / (2.0f * PIf), 1.0f - (theta / PIf), 0.0f);
+    const float sinTheta = std::sin(theta), cosTheta = std::cos(theta), sinPhi = std::sin(phi), cosPhi = std::cos(phi);
+    hInfo.dpdu = V3(-sinTheta * sinPhi * 2.0f * PIf, sinTheta * cosPhi * 2.0f * PIf, 0.0f);
+    hInfo.dpdv = V3(-PIf * cosTheta * cosPhi, -PIf * cosTheta * sinPhi, PIf * sinTheta);
+    hInfo.face = 0;
+    hInfo.mtlID = 0;
+    return true;
+}
+
+// objects.cpp:89-126 (square [-1,1]^2 at z = 0, normal +z)
+bool Mesh::intersect_plane(const Ray& ray, Hit& hInfo, int hitSide) const {
+    const float denom = ray.dir.z;
+    if (std::fabs(denom) < EPS) return false;
+    const float t = -(ray.p.z) / denom;
+    if (t <= EPS || t >= hInfo.z) return false;
+    const bool front = denom < 0.0f;
+    if ((hitSide == RTX_HIT_FRONT && !front) || (hitSide == RTX_HIT_BACK && front)) return false;
+    const V3 hp = ray.p + ray.dir * t;
+    if (hp.x < -1.0f || hp.x > 1.0f) return false;
+    if (hp.y < -1.0f || hp.y > 1.0f) return false;
+    hInfo.z = t;
+    hInfo.p = hp;
+    hInfo.GN = V3(0, 0, 1);
+    hInfo.N = V3(0, 0, 1);
+    hInfo.front = front;
+    hInfo.uvw = V3(0.5f * (hp.x + 1.0f), 0.5f * (hp.y + 1.0f), 0.0f);
+    hInfo.dpdu = V3(2.0f, 0.0f, 0.0f);
+    hInfo.dpdv = V3(0.0f, 2.0f, 0.0f);
+    hInfo.face = 0;
+    hInfo.mtlID = 0;
+    return true;
+}
+
 bool Mesh::intersect_ray(const Ray& ray, Hit& hInfo, int hitSide, bool useBVH, uint64_t* counters) const {
+    if (kind == RTX_OBJ_SPHERE) return intersect_sphere(ray, hInfo, hitSide);
+    if (kind == RTX_OBJ_PLANE) return intersect_plane(ray, hInfo, hitSide);
     if (useBVH) {
         if (nf == 0) return false;
         if (!bounds.empty() && !bounds.intersect(ray, hInfo.z)) return false;
@@ -357,6 +422,25 @@ Scene* scene_from_desc(const rtx_scene_desc* d) {
     for (int i = 0; i < d->n_meshes; ++i) {
         const rtx_mesh_desc& md = d->meshes[i];
         Mesh& m = s->meshes[i];
+        if (md.kind != RTX_OBJ_MESH) {
+            // Sphere::GetBoundBox = [-1,1]^3, Plane::GetBoundBox = [-1,1]^2 x {0}
+            m.kind = md.kind;
+            m.nf = 1;
+            m.bounds.add(V3(-1, -1, md.kind == RTX_OBJ_PLANE ? 0.0f : -1.0f));
+            m.bounds.add(V3(1, 1, md.kind == RTX_OBJ_PLANE ? 0.0f : 1.0f));
+            std::memcpy(m.tm.m, md.xform, sizeof(float) * 12);
+            m.identity = is_identity(m.tm);
+            m.itm = m.identity ? m.tm : invert(m.tm);
+            m.material = md.material;
+            s->faceBase.push_back(base);
+            base += 1;
+            for (int c = 0; c < 8; ++c) {
+                V3 p((c & 1) ? m.bounds.pmax.x : m.bounds.pmin.x, (c & 2) ? m.bounds.pmax.y : m.bounds.pmin.y,
+                     (c & 4) ? m.bounds.pmax.z : m.bounds.pmin.z);
+                s->rootBox.add(m.identity ? p : xf_point(m.tm, p));
+            }
+            continue;
+        }
         m.V.resize(md.nv);
         for (int k = 0; k < md.nv; ++k) m.V[k] = V3(md.v[3 * k], md.v[3 * k + 1], md.v[3 * k + 2]);
         m.nf = md.nf;

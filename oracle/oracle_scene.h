@@ -4,6 +4,7 @@
 //   Box::IntersectRay                      RayTracer/scene_box.cpp:8-46
 //   TriObj::IntersectTriangle              RayTracer/objects.cpp:140-243
 //   TriObj::IntersectRay / brute force     RayTracer/objects.cpp:245-266
+//   Sphere::IntersectRay / Plane::IntersectRay  RayTracer/objects.cpp:21-126
 //   TriObj::TraceBVHNode                   RayTracer/triobj_bvh.cpp:13-34
 //   IntersectNodeLocal / IntersectNode     RayTracer/IntersectNodeAdapter.h:23-108
 //   IntersectSceneWithLights               RayTracer/IntersectNodeAdapter.h:111-151
@@ -93,6 +94,7 @@ struct Mesh {
     M34 tm, itm;
     bool identity = true;
     int material = -1;
+    int kind = RTX_OBJ_MESH;   // RTX_OBJ_SPHERE / RTX_OBJ_PLANE: analytic object in object space (nf = 1)
     // own BVH2, leaf <= 4 faces (objects.cpp:136 bvh.SetMesh(this,4))
     struct Node {
         float b[6];
@@ -108,6 +110,8 @@ struct Mesh {
     bool intersect_triangle(const Ray& ray, Hit& h, int hitSide, int faceID) const;
     bool trace_bvh(const Ray& ray, Hit& h, int hitSide, int nodeID, uint64_t* counters) const;
     bool intersect_ray(const Ray& ray, Hit& h, int hitSide, bool useBVH, uint64_t* counters) const;
+    bool intersect_sphere(const Ray& ray, Hit& h, int hitSide) const;   // Sphere::IntersectRay objects.cpp:21-86
+    bool intersect_plane(const Ray& ray, Hit& h, int hitSide) const;    // Plane::IntersectRay  objects.cpp:89-126
 };
 
 struct TexMap {

@@ -13,6 +13,7 @@ c_int_p = C.POINTER(C.c_int)
 HIT_FRONT, HIT_BACK, HIT_FRONT_AND_BACK = 1, 2, 3
 BIGFLOAT = 1.0e30
 MTL_BLINN, MTL_PHONG = 0, 1
+OBJ_MESH, OBJ_SPHERE, OBJ_PLANE = 0, 1, 2
 TEX_RGB8, TEX_RGB32F = 0, 1
 FILTER_TENT, FILTER_GAUSSIAN, FILTER_MITCHELL, FILTER_LANCZOS = 0, 1, 2, 3
 
@@ -20,7 +21,7 @@ FILTER_TENT, FILTER_GAUSSIAN, FILTER_MITCHELL, FILTER_LANCZOS = 0, 1, 2, 3
 class MeshDesc(C.Structure):
     _fields_ = [("v", c_float_p), ("nv", C.c_int), ("vn", c_float_p), ("nvn", C.c_int), ("vt", c_float_p),
                 ("nvt", C.c_int), ("f", c_int_p), ("fn", c_int_p), ("ft", c_int_p), ("face_mtl", c_int_p),
-                ("nf", C.c_int), ("xform", C.c_float * 12), ("material", C.c_int)]
+                ("nf", C.c_int), ("xform", C.c_float * 12), ("material", C.c_int), ("kind", C.c_int)]
 
 
 class TexMapDesc(C.Structure):

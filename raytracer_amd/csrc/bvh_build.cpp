@@ -133,8 +133,9 @@ struct Builder {
 };
 
 struct SrcTri {
-    float v[3][3];
+    float v[3][3];          // analytic object: v[0] = world box min, v[1] = v[2] = world box max
     int obj, face;
+    int kind;
 };
 
 inline void xf_point(const float* M, const float* p, float* o) {
@@ -183,9 +184,17 @@ struct Emitter {
         // e1 = v1 - v0, e2 = v2 - v0 in fp32: the operands the reference forms per test (objects.cpp:146-147)
         r.e1x = t.v[1][0] - t.v[0][0]; r.e1y = t.v[1][1] - t.v[0][1]; r.e1z = t.v[1][2] - t.v[0][2];
         r.e2x = t.v[2][0] - t.v[0][0]; r.e2y = t.v[2][1] - t.v[0][1]; r.e2z = t.v[2][2] - t.v[0][2];
-        r.pad0 = r.pad1 = 0.0f;
+        r.kind = (uint32_t)t.kind;
+        r.obj = (uint32_t)t.obj;
         r.prim = (uint32_t)(faceBase[t.obj] + t.face);
         out.tris.push_back(r);
+        if (t.kind != RTX_OBJ_MESH) {
+            TriAttr a;
+            std::memset(&a, 0, sizeof(a));
+            a.obj_mtl = (uint32_t)t.obj;
+            out.attrs.push_back(a);
+            return;
+        }
 
         const rtx_mesh_desc& m = desc->meshes[t.obj];
         TriAttr a;
@@ -334,7 +343,11 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
     size_t total = 0;
     for (int m = 0; m < desc->n_meshes; ++m) {
         const rtx_mesh_desc& md = desc->meshes[m];
-        if (md.nf < 0 || md.nv < 0 || (md.nf > 0 && (!md.v || !md.f))) {
+        if (md.kind != RTX_OBJ_MESH && md.kind != RTX_OBJ_SPHERE && md.kind != RTX_OBJ_PLANE) {
+            err = "object " + std::to_string(m) + ": unknown kind";
+            return false;
+        }
+        if (md.kind == RTX_OBJ_MESH && (md.nf < 0 || md.nv < 0 || (md.nf > 0 && (!md.v || !md.f)))) {
             err = "mesh " + std::to_string(m) + ": missing vertex/face arrays";
             return false;
         }
@@ -343,7 +356,7 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
             return false;
         }
         faceBase[m] = (int)total;
-        total += (size_t)md.nf;
+        total += md.kind == RTX_OBJ_MESH ? (size_t)md.nf : 1u;   // an analytic object counts as one primitive
     }
     if (total > (size_t)(1u << 27)) {
         err = "more than 2^27 triangles";
@@ -356,6 +369,11 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
         else invert34(desc->meshes[m].xform, &itm[12 * (size_t)m]);
     }
     out.objs.resize(desc->n_meshes);
+    out.objXf.resize(std::max(1, desc->n_meshes));
+    for (int m = 0; m < desc->n_meshes; ++m) {
+        std::memcpy(out.objXf[m].fwd, desc->meshes[m].xform, 48);
+        std::memcpy(out.objXf[m].inv, &itm[12 * (size_t)m], 48);
+    }
     AABB rootBox;
     for (int m = 0; m < desc->n_meshes; ++m) {
         const rtx_mesh_desc& md = desc->meshes[m];
@@ -364,6 +382,31 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
         o.material = md.material;
         o.flags = ((md.vn && md.nvn > 0) ? OBJ_HAS_NORMALS : 0u) | ((md.vt && md.nvt > 0) ? OBJ_HAS_TEXCOORDS : 0u);
         o.face_base = faceBase[m];
+        if (md.kind != RTX_OBJ_MESH) {
+            // Sphere: GetBoundBox = [-1,1]^3, Plane: [-1,1]^2 x {0}; corners to root coordinates
+            o.flags = OBJ_HAS_TEXCOORDS;
+            o.nf = 1;
+            AABB wb;
+            for (int c = 0; c < 8; ++c) {
+                float p[3] = {(c & 1) ? 1.0f : -1.0f, (c & 2) ? 1.0f : -1.0f, md.kind == RTX_OBJ_PLANE ? 0.0f : ((c & 4) ? 1.0f : -1.0f)};
+                float w[3];
+                xf_point(md.xform, p, w);
+                if (!std::isfinite(w[0]) || !std::isfinite(w[1]) || !std::isfinite(w[2])) {
+                    err = "object " + std::to_string(m) + ": non-finite transform";
+                    return false;
+                }
+                wb.add(w);
+            }
+            rootBox.add(wb);
+            SrcTri& t = src[(size_t)faceBase[m]];
+            t.obj = m;
+            t.face = 0;
+            t.kind = md.kind;
+            std::memcpy(t.v[0], wb.lo, 12);
+            std::memcpy(t.v[1], wb.hi, 12);
+            std::memcpy(t.v[2], wb.hi, 12);
+            continue;
+        }
         o.nf = md.nf;
         for (int k = 0; k < 3 * md.nv; ++k)
             if (!std::isfinite(md.v[k])) {
@@ -388,6 +431,7 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
             SrcTri& t = src[(size_t)faceBase[m] + f];
             t.obj = m;
             t.face = f;
+            t.kind = RTX_OBJ_MESH;
             for (int k = 0; k < 3; ++k) {
                 int vi = md.f[3 * (size_t)f + k];
                 if (vi < 0 || vi >= md.nv) {

@@ -12,6 +12,7 @@ struct HostScene {
     std::vector<TriRec> tris;
     std::vector<TriAttr> attrs;
     std::vector<ObjRec> objs;
+    std::vector<ObjXform> objXf;
     uint32_t root = RTX_EMPTY_CHILD;
     float bounds[6] = {1e30f, 1e30f, 1e30f, -1e30f, -1e30f, -1e30f};
     int depth = 0;

@@ -38,8 +38,11 @@ static_assert(sizeof(Node4) == 64, "Node4 must be 64 bytes");
 struct TriRec {
     float v0x, v0y, v0z;
     uint32_t prim;          // global triangle id = faceBase[obj] + face (object order, then face order)
-    float e1x, e1y, e1z, pad0;
-    float e2x, e2y, e2z, pad1;
+    float e1x, e1y, e1z;
+    uint32_t kind;          // 0 = triangle; RTX_OBJ_SPHERE / RTX_OBJ_PLANE: analytic object, then v0 = world box
+                            // min, e1 = e2 = box extent (so v0, v0+e1 span its box) and `obj` names its transform
+    float e2x, e2y, e2z;
+    uint32_t obj;           // object index (analytic records only)
 };
 static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
 
@@ -57,6 +60,11 @@ struct ObjRec {
     uint32_t flags;
     int face_base;          // first global triangle id of this object
     int nf;
+};
+// object <-> world transforms (Node::ToNodeCoords / FromNodeCoords), used by analytic objects only
+struct ObjXform {
+    float fwd[12];          // object -> world, 3x4 row-major
+    float inv[12];          // world -> object
 };
 
 struct DevTexMap {
@@ -91,6 +99,7 @@ struct DevScene {
     const TriRec* tris;
     const TriAttr* attrs;
     const ObjRec* objs;
+    const ObjXform* objXf;
     const DevMaterial* mtls;
     const DevTexMap* texmaps;
     uint32_t root;          // child reference of the root (a leaf reference for tiny scenes)

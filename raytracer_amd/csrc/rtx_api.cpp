@@ -121,6 +121,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     CHECK_RC(upload(s, hs.tris, &d.tris));
     CHECK_RC(upload(s, hs.attrs, &d.attrs));
     CHECK_RC(upload(s, hs.objs, &d.objs));
+    CHECK_RC(upload(s, hs.objXf, &d.objXf));
     d.root = hs.root;
     d.n_tris = (int)hs.tris.size();
     d.n_nodes = (int)hs.nodes.size();

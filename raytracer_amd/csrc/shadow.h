@@ -12,10 +12,18 @@ __device__ __forceinline__ f3 offset_point(f3 p, f3 n, f3 dir) {
 }
 
 // Geometric normal + front flag of a triangle hit (objects.cpp:175-177,190) without the rest of HitInfo.
-__device__ __forceinline__ void triangle_gn(const DevScene& sc, const RayT& r, int slot, f3& GN, bool& front, int& obj) {
+__device__ __forceinline__ void triangle_gn(const DevScene& sc, const RayT& r, int slot, float t, f3& GN, bool& front, int& obj) {
     const float4* tris4 = reinterpret_cast<const float4*>(sc.tris);
     const float4 b = tris4[(size_t)slot * 3 + 1];
     const float4 c = tris4[(size_t)slot * 3 + 2];
+    if (__float_as_uint(b.w) != 0u) {   // Sphere / Plane
+        SurfHit sh;
+        resolve_analytic(sc, __float_as_uint(b.w), __float_as_uint(c.w), r, HitT{t, 0.0f, 0.0f, slot}, sh);
+        GN = sh.GN;
+        front = sh.front;
+        obj = sh.obj;
+        return;
+    }
     GN = cross3(mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z));
     const float l2 = len2_3(GN);
     if (l2 > 0.0f) GN = GN / sqrtf(l2);
@@ -41,7 +49,7 @@ __device__ __forceinline__ bool shadow_hop_end(const DevScene& sc, f3& o, f3 d, 
     bool front;
     int obj;
     const RayT r{o.x, o.y, o.z, d.x, d.y, d.z, maxDist};
-    triangle_gn(sc, r, h.slot, GN, front, obj);
+    triangle_gn(sc, r, h.slot, h.t, GN, front, obj);
     const int mi = sc.objs[obj].material;
     if (mi < 0) return true;
     const DevMaterial& m = sc.mtls[mi];

@@ -71,12 +71,59 @@ __device__ __forceinline__ f3 eval_tc(const DevScene& sc, const float* value, in
     return c;
 }
 
+// HitInfo of a Sphere / Plane hit (objects.cpp:47-85, :100-125) followed by Node::FromNodeCoords
+// (IntersectNodeAdapter.h:93; framework convention as in the oracle: p by the node transform, normals by the
+// transposed inverse without renormalising, dpdu/dpdv as vectors).
+__device__ __forceinline__ void resolve_analytic(const DevScene& sc, uint32_t kind, uint32_t obj, const RayT& r, const HitT& h,
+                                                 SurfHit& s) {
+    float p[3], d[3];
+    ray_to_object(sc, obj, r, p, d);
+    const f3 hp = mk3(p[0] + d[0] * h.t, p[1] + d[1] * h.t, p[2] + d[2] * h.t);
+    f3 GN, dpdu, dpdv, uvw;
+    if (kind == RTX_OBJ_SPHERE) {
+        GN = normalized3(hp);
+        const f3 n = GN;
+        const float PIf = 3.14159265358979323846f;
+        const float phi = atan2f(n.y, n.x);
+        const float theta = acosf(fminf(1.0f, fmaxf(-1.0f, n.z)));
+        uvw = mk3((phi + PIf) / (2.0f * PIf), 1.0f - (theta / PIf), 0.0f);
+        const float sinTheta = sinf(theta), cosTheta = cosf(theta), sinPhi = sinf(phi), cosPhi = cosf(phi);
+        dpdu = mk3(-sinTheta * sinPhi * 2.0f * PIf, sinTheta * cosPhi * 2.0f * PIf, 0.0f);
+        dpdv = mk3(-PIf * cosTheta * cosPhi, -PIf * cosTheta * sinPhi, PIf * sinTheta);
+    } else {
+        GN = mk3(0.0f, 0.0f, 1.0f);
+        uvw = mk3(0.5f * (hp.x + 1.0f), 0.5f * (hp.y + 1.0f), 0.0f);
+        dpdu = mk3(2.0f, 0.0f, 0.0f);
+        dpdv = mk3(0.0f, 2.0f, 0.0f);
+    }
+    s.front = kind == RTX_OBJ_SPHERE ? (d[0] * GN.x + d[1] * GN.y + d[2] * GN.z) < 0.0f : d[2] < 0.0f;
+    const ObjXform& X = sc.objXf[obj];
+    const float* F = X.fwd;
+    const float* I = X.inv;
+    s.p = xf_point3(F, hp);
+    s.GN = mk3(I[0] * GN.x + I[4] * GN.y + I[8] * GN.z, I[1] * GN.x + I[5] * GN.y + I[9] * GN.z,
+               I[2] * GN.x + I[6] * GN.y + I[10] * GN.z);
+    s.N = s.GN;
+    s.dpdu = xf_vec3(F, dpdu);
+    s.dpdv = xf_vec3(F, dpdv);
+    s.uvw = uvw;
+    s.t = h.t;
+    s.obj = (int)obj;
+    s.mtlID = 0;
+    s.face = 0;
+    s.light = -1;
+}
+
 // HitInfo of a triangle hit: objects.cpp:172-240
 __device__ __forceinline__ void resolve_triangle(const DevScene& sc, const RayT& r, const HitT& h, SurfHit& s) {
     const float4* tris4 = reinterpret_cast<const float4*>(sc.tris);
     const float4 a = tris4[(size_t)h.slot * 3 + 0];
     const float4 b = tris4[(size_t)h.slot * 3 + 1];
     const float4 c = tris4[(size_t)h.slot * 3 + 2];
+    if (__float_as_uint(b.w) != 0u) {
+        resolve_analytic(sc, __float_as_uint(b.w), __float_as_uint(c.w), r, h, s);
+        return;
+    }
     const float4* at4 = reinterpret_cast<const float4*>(sc.attrs + h.slot);
     const float4 q0 = at4[0], q1 = at4[1], q2 = at4[2], q3 = at4[3];
     const uint32_t obj_mtl = __float_as_uint(q3.w);

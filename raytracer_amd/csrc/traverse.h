@@ -97,6 +97,68 @@ __device__ __forceinline__ void test_triangle(const float4 a, const float4 b, co
     bestPrim = prim;
 }
 
+// Analytic objects (one record per object, TriRec::kind != 0): the ray goes to object space with the node's inverse
+// transform, direction not renormalised, so t is the same parameter in both spaces (Node::ToNodeCoords,
+// IntersectNodeAdapter.h:62). Sphere::IntersectRay objects.cpp:21-51, Plane::IntersectRay objects.cpp:89-104.
+__device__ __forceinline__ void ray_to_object(const DevScene& sc, uint32_t obj, const RayT& r, float p[3], float d[3]) {
+    const float* M = sc.objXf[obj].inv;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        p[k] = M[4 * k] * r.ox + M[4 * k + 1] * r.oy + M[4 * k + 2] * r.oz + M[4 * k + 3];
+        d[k] = M[4 * k] * r.dx + M[4 * k + 1] * r.dy + M[4 * k + 2] * r.dz;
+    }
+}
+__device__ __forceinline__ void test_analytic(const DevScene& sc, uint32_t kind, uint32_t obj, uint32_t prim, const RayT& r,
+                                              int hitSide, uint32_t slot, HitT& best, uint32_t& bestPrim) {
+#pragma clang fp contract(off)
+    float p[3], d[3];
+    ray_to_object(sc, obj, r, p, d);
+    float t;
+    bool front;
+    if (kind == RTX_OBJ_SPHERE) {
+        const float A = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        const float B = 2.0f * (p[0] * d[0] + p[1] * d[1] + p[2] * d[2]);
+        const float C = (p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) - 1.0f;
+        const float disc = B * B - 4 * A * C;
+        if (disc < 0.0f) return;
+        const float s = sqrtf(disc);
+        const float inv2A = 0.5f / A;
+        const float t0 = (-B - s) * inv2A;
+        const float t1 = (-B + s) * inv2A;
+        t = -1.0f;
+        if (t0 > RTX_EPS) t = t0;
+        else if (t1 > RTX_EPS) t = t1;
+        if (t < 0.0f || t > best.t) return;
+        const float hx = p[0] + d[0] * t, hy = p[1] + d[1] * t, hz = p[2] + d[2] * t;
+        const float len = sqrtf(hx * hx + hy * hy + hz * hz);
+        front = (d[0] * (hx / len) + d[1] * (hy / len) + d[2] * (hz / len)) < 0.0f;
+    } else {
+        const float denom = d[2];
+        if (fabsf(denom) < RTX_EPS) return;
+        t = -p[2] / denom;
+        if (t <= RTX_EPS || t > best.t) return;
+        front = denom < 0.0f;
+    }
+    if ((hitSide == RTX_HIT_FRONT && !front) || (hitSide == RTX_HIT_BACK && front)) return;
+    if (kind == RTX_OBJ_PLANE) {
+        const float hx = p[0] + d[0] * t, hy = p[1] + d[1] * t;
+        if (hx < -1.0f || hx > 1.0f) return;
+        if (hy < -1.0f || hy > 1.0f) return;
+    }
+    if (t == best.t && (best.slot < 0 || prim >= bestPrim)) return;   // t >= hInfo.z rejects; ties: smaller id wins
+    best.t = t;
+    best.u = 0.0f;
+    best.v = 0.0f;
+    best.slot = (int)slot;
+    bestPrim = prim;
+}
+__device__ __forceinline__ void test_primitive(const DevScene& sc, const float4 a, const float4 b, const float4 c, const RayT& r,
+                                               int hitSide, uint32_t slot, HitT& best, uint32_t& bestPrim) {
+    const uint32_t kind = __float_as_uint(b.w);
+    if (kind != 0u) test_analytic(sc, kind, __float_as_uint(c.w), __float_as_uint(a.w), r, hitSide, slot, best, bestPrim);
+    else test_triangle(a, b, c, r, hitSide, slot, sc.tris, best, bestPrim);
+}
+
 // ---- traversal as a small state machine -------------------------------------------------------------------
 // cur: RTX_TRAV_DONE, an inner-node index, or a leaf reference. The kernels run it "while-while": all lanes of a
 // wave first descend inner nodes until each holds a leaf (or is done), then all test their leaves together, so
@@ -226,7 +288,7 @@ __device__ __forceinline__ uint32_t trav_leaf_step(TravState& s, const DevScene&
         const float4 a = tris4[(size_t)slot * 3 + 0];
         const float4 b = tris4[(size_t)slot * 3 + 1];
         const float4 c = tris4[(size_t)slot * 3 + 2];
-        test_triangle(a, b, c, s.r, hitSide, slot, sc.tris, s.best, s.bestPrim);
+        test_primitive(sc, a, b, c, s.r, hitSide, slot, s.best, s.bestPrim);
     }
     trav_pop(s, st);
     return cnt;

@@ -29,7 +29,7 @@ public:
     GpuScene(const GpuScene&) = delete;
     GpuScene& operator=(const GpuScene&) = delete;
     rtx_scene* Handle() const { return handle; }
-    // (Node, Object) pair of flattened object index i, in CollectSceneNodeObjects order restricted to TriObj
+    // (Node, Object) pair of flattened object index i, in CollectSceneNodeObjects order (TriObj, Sphere, Plane)
     const Node* NodeOf(int obj) const { return obj >= 0 && obj < (int)nodes.size() ? nodes[obj] : nullptr; }
     const std::vector<Light*>& Lights() const { return lights; }
 
@@ -98,7 +98,17 @@ private:
         std::vector<rtx_mesh_desc> meshes;
         for (auto const& it : items) {
             auto tri = dynamic_cast<const TriObj*>(it.node->GetNodeObj());
-            if (!tri) continue;   // Sphere / Plane are not instanced by the reference scene; not handled on the GPU path yet
+            if (!tri) {
+                const bool sphere = dynamic_cast<const Sphere*>(it.node->GetNodeObj()) != nullptr;
+                if (!sphere && !dynamic_cast<const Plane*>(it.node->GetNodeObj())) continue;   // unknown Object subclass
+                rtx_mesh_desc d{};
+                d.kind = sphere ? RTX_OBJ_SPHERE : RTX_OBJ_PLANE;
+                for (int k = 0; k < 12; ++k) d.xform[k] = it.world.m[k];
+                d.material = mtlOf(it.node->GetMaterial());
+                meshes.push_back(d);
+                nodes.push_back(it.node);
+                continue;
+            }
             static_assert(sizeof(Vec3f) == 12 && sizeof(TriObj::TriFace) == 12, "tightly packed arrays expected");
             rtx_mesh_desc d{};
             d.v = &tri->v.data()->x;  d.nv = (int)tri->v.size();

@@ -73,6 +73,8 @@ struct Ray {
 
 struct Box {
     Vec3f pmin{BIGFLOAT, BIGFLOAT, BIGFLOAT}, pmax{-BIGFLOAT, -BIGFLOAT, -BIGFLOAT};
+    Box() = default;
+    Box(Vec3f lo, Vec3f hi) : pmin(lo), pmax(hi) {}
     bool IsEmpty() const { return pmin.x > pmax.x || pmin.y > pmax.y || pmin.z > pmax.z; }
 };
 
@@ -161,6 +163,17 @@ class Object {
 public:
     virtual ~Object() = default;
     virtual Box GetBoundBox() const = 0;
+};
+
+// Unit sphere at the origin of object space (objects.cpp:21-86) and the square [-1,1]^2 at z = 0 (objects.cpp:89-126);
+// both are intersected on the GPU in object space under their node's transform.
+class Sphere : public Object {
+public:
+    Box GetBoundBox() const override { return Box(Vec3f(-1, -1, -1), Vec3f(1, 1, 1)); }
+};
+class Plane : public Object {
+public:
+    Box GetBoundBox() const override { return Box(Vec3f(-1, -1, 0), Vec3f(1, 1, 0)); }
 };
 
 // Triangle mesh with cy::TriMesh's accessors (V/VN/VT, F/FN/FT); BuildAcceleration only records the bounds: the

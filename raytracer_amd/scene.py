@@ -12,7 +12,9 @@ IDENTITY = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float32)
 
 
 class Mesh:
-    def __init__(self, v, f, vn=None, vt=None, fn=None, ft=None, face_mtl=None, xform=None, material=-1, name=""):
+    def __init__(self, v, f, vn=None, vt=None, fn=None, ft=None, face_mtl=None, xform=None, material=-1, name="",
+                 kind=_ffi.OBJ_MESH):
+        self.kind = int(kind)
         self.v = np.ascontiguousarray(v, dtype=np.float32).reshape(-1, 3)
         self.f = np.ascontiguousarray(f, dtype=np.int32).reshape(-1, 3)
         self.vn = None if vn is None else np.ascontiguousarray(vn, dtype=np.float32).reshape(-1, 3)
@@ -26,7 +28,19 @@ class Mesh:
 
     @property
     def nf(self):
-        return self.f.shape[0]
+        return self.f.shape[0] if self.kind == _ffi.OBJ_MESH else 1   # an analytic object is one primitive
+
+    @classmethod
+    def sphere(cls, xform=None, material=-1, name="sphere"):
+        """Unit sphere in object space (Sphere, objects.cpp:21-86) under the object->world transform `xform`."""
+        return cls(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32), xform=xform, material=material, name=name,
+                   kind=_ffi.OBJ_SPHERE)
+
+    @classmethod
+    def plane(cls, xform=None, material=-1, name="plane"):
+        """Square [-1,1]^2 at z = 0 in object space (Plane, objects.cpp:89-126)."""
+        return cls(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32), xform=xform, material=material, name=name,
+                   kind=_ffi.OBJ_PLANE)
 
 
 class Material:
@@ -100,6 +114,7 @@ class SceneData:
                 d.face_mtl = ip(m.face_mtl)
             d.xform = (C.c_float * 12)(*m.xform.tolist())
             d.material = m.material
+            d.kind = m.kind
         mats = (_ffi.MaterialDesc * max(1, len(self.materials)))()
         for i, m in enumerate(self.materials):
             d = mats[i]

@@ -96,6 +96,19 @@ int main() {
     fl->SetNodeObj(floorObj);
     fl->SetMaterial(white);
     scene.rootNode.AppendChild(fl);
+    // analytic objects (objects.cpp:21-126): an ellipsoid and a tilted square mirror
+    Node* sp = new Node();
+    sp->SetNodeObj(std::make_shared<Sphere>());
+    sp->SetMaterial(red);
+    sp->tm.m[0] = 0.6f; sp->tm.m[5] = 0.4f; sp->tm.m[10] = 0.5f;
+    sp->tm.m[3] = -1.8f; sp->tm.m[7] = 0.6f; sp->tm.m[11] = 1.4f;
+    scene.rootNode.AppendChild(sp);
+    Node* pl = new Node();
+    pl->SetNodeObj(std::make_shared<Plane>());
+    pl->SetMaterial(white);
+    pl->tm.m[0] = 1.5f; pl->tm.m[5] = 0.0f; pl->tm.m[6] = -1.5f; pl->tm.m[9] = 1.5f; pl->tm.m[10] = 0.0f;   // rotate 90 deg about x, scale 1.5
+    pl->tm.m[3] = 0.5f; pl->tm.m[7] = 1.0f; pl->tm.m[11] = -3.0f;
+    scene.rootNode.AppendChild(pl);
     PointLight* L = scene.AddPointLight();
     L->position = Vec3f(1, 6, 2);
     L->intensity = Color(20, 18, 15);
@@ -105,7 +118,9 @@ int main() {
     // CollectSceneNodeObjects: DFS pre-order (SceneAdapter.h:8-18)
     std::vector<std::pair<const Node*, const Object*>> no;
     CollectSceneNodeObjects(scene, no);
-    CHECK(no.size() == 4 && no[0].first == a && no[1].first == b && no[2].first == c && no[3].first == fl, "DFS order");
+    CHECK(no.size() == 6 && no[0].first == a && no[1].first == b && no[2].first == c && no[3].first == fl && no[4].first == sp &&
+              no[5].first == pl,
+          "DFS order");
 
     // the same flattened description for the oracle
     std::vector<rtx_mesh_desc> meshes;
@@ -134,9 +149,17 @@ int main() {
         d.material = mi[k];
         meshes.push_back(d);
     }
+    for (int k = 4; k < 6; ++k) {
+        rtx_mesh_desc d{};
+        d.kind = k == 4 ? RTX_OBJ_SPHERE : RTX_OBJ_PLANE;
+        const Matrix34& w = k == 4 ? sp->tm : pl->tm;
+        for (int q = 0; q < 12; ++q) d.xform[q] = w.m[q];
+        d.material = k == 4 ? 0 : 1;
+        meshes.push_back(d);
+    }
     rtx_light_desc ld{{1, 6, 2}, {20, 18, 15}, 0.8f, 1.0f};
     rtx_scene_desc sd{};
-    sd.meshes = meshes.data(); sd.n_meshes = 4;
+    sd.meshes = meshes.data(); sd.n_meshes = 6;
     sd.materials = mtls.data(); sd.n_materials = 3;
     sd.lights = &ld; sd.n_lights = 1;
     sd.environment[0] = 0.3f; sd.environment[1] = 0.35f; sd.environment[2] = 0.4f;

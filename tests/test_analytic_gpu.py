@@ -1,0 +1,84 @@
+"""Sphere and Plane objects (reference RayTracer/objects.cpp:21-126) in the same flattened BVH as the meshes:
+closest hit, full HitInfo, visibility and a short path-traced render against the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+from raytracer_amd import _ffi, synth
+from raytracer_amd.scene import SceneData, Mesh, Material, Light, make_camera, render_params
+from tests.helpers import random_rays, compare_hits
+from tests.oracle_ffi import OracleScene
+
+pytestmark = pytest.mark.gpu
+
+
+def _xf(scale, rot_z, t):
+    c, s = np.cos(rot_z), np.sin(rot_z)
+    R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], np.float32) @ np.diag(np.asarray(scale, np.float32))
+    return np.concatenate([R, np.asarray(t, np.float32)[:, None]], axis=1).astype(np.float32).reshape(12)
+
+
+@pytest.fixture(scope="module")
+def mixed(rtx):
+    V, N, UV, F = synth.torus(1.0, 0.3, 24, 12)
+    sd = SceneData()
+    sd.materials = [Material("matte", diffuse=(0.7, 0.6, 0.5), specular=(0.2, 0.2, 0.2), glossiness=30.0),
+                    Material("glass", diffuse=(0, 0, 0), specular=(0.8, 0.8, 0.8), refraction=(0.9, 0.9, 0.9), ior=1.5,
+                             glossiness=1000.0),
+                    Material("mirror", diffuse=(0.1, 0.1, 0.1), reflection=(0.8, 0.8, 0.8), glossiness=500.0)]
+    sd.meshes = [Mesh(V, F, vn=N, vt=UV, material=0),
+                 Mesh.sphere(_xf((0.6, 0.6, 0.6), 0.0, (0.0, 0.0, 0.9)), material=1),          # uniform scale
+                 Mesh.sphere(_xf((0.9, 0.4, 0.3), 0.5, (1.8, 0.3, 0.2)), material=2),          # ellipsoid
+                 Mesh.plane(_xf((4.0, 4.0, 1.0), 0.3, (0.0, 0.0, -0.5)), material=0),           # floor
+                 Mesh.plane(np.array([1, 0, 0, 0, 0, 0, -1, 2.5, 0, 1, 0, 1.0], np.float32) * 1.0, material=2),  # wall
+                 Mesh.sphere(None, material=0)]                                                  # identity, inside torus
+    sd.lights = [Light((2.0, -3.0, 4.0), (30.0, 30.0, 30.0), 0.5, 1.0), Light((-3.0, 1.0, 3.0), (15.0, 15.0, 20.0), 0.0, 1.0)]
+    sd.environment = (0.3, 0.35, 0.4)
+    return sd, rtx.Scene(sd), OracleScene(sd)
+
+
+@pytest.mark.parametrize("side", [_ffi.HIT_FRONT, _ffi.HIT_BACK, _ffi.HIT_FRONT_AND_BACK])
+def test_closest_hit_with_spheres_and_planes(mixed, side):
+    sd, gs, osc = mixed
+    rays = random_rays(np.random.default_rng(21), 40000, osc.bounds())
+    g = gs.trace_closest(rays, side)
+    o = osc.trace_closest(rays, side)
+    same, hit = compare_hits(g, o, gs.face_base, id_tol=2e-3, t_rel=1e-4)
+    kinds = np.array([m.kind for m in sd.meshes])
+    analytic = hit & (kinds[np.maximum(g["obj"], 0)] != _ffi.OBJ_MESH)
+    assert analytic.sum() > 2000
+    # HitInfo of the analytic hits (world space after FromNodeCoords)
+    for k, tol in (("p", 1e-4), ("N", 1e-4), ("GN", 1e-4), ("uvw", 2e-4), ("dpdu", 2e-3), ("dpdv", 2e-3)):
+        d = np.abs(g[k][analytic] - o[k][analytic])
+        if k == "uvw":   # u wraps at the sphere's seam
+            d[:, 0] = np.minimum(d[:, 0], 1.0 - d[:, 0])
+        assert d.max() <= tol * max(1.0, np.abs(o[k][analytic]).max()), (k, d.max())
+    assert (g["front"][analytic] == o["front"][analytic]).all()
+    # the object-space test keeps t within 1e-5 on the analytic objects themselves
+    rel = np.abs(g["t"][analytic] - o["t"][analytic]) / o["t"][analytic]
+    assert rel.max() <= 1e-5
+
+
+def test_visibility_through_analytic_glass(mixed):
+    sd, gs, osc = mixed
+    rng = np.random.default_rng(22)
+    rays = random_rays(rng, 20000, osc.bounds(), tmax=6.0)
+    normals = -rays["d"].copy()
+    for tr in (True, False):
+        g = gs.trace_visibility(rays, normals, tr)
+        o = osc.trace_visibility(rays, normals, tr)
+        assert (np.abs(g - o) <= 1e-5).mean() >= 0.999
+
+
+def test_path_tracing_with_analytic_objects(mixed):
+    sd, gs, osc = mixed
+    cam = make_camera(pos=(0.5, -6.0, 2.5), target=(0.5, 0.0, 0.3), up=(0, 0, 1), fov=40.0, width=64, height=48)
+    rp = render_params(spp_min=8, max_bounces=6)
+    g, _ = gs.render_samples(cam, rp)
+    o = osc.render_samples(cam, rp)
+    assert np.isfinite(g).all()
+    pd_ok = np.abs(g[..., 3] - o[..., 3]) <= 1e-4 * np.abs(o[..., 3])
+    assert pd_ok.mean() >= 0.999
+    d = np.abs(g[..., :3] - o[..., :3]).max(-1)
+    ok = d <= 1e-3 * (1 + np.abs(o[..., :3]).max(-1))
+    assert ok.mean() >= 0.99, ok.mean()
+    assert o[..., :3].mean() > 0.01
