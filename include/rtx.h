@@ -273,6 +273,28 @@ int rtx_render_accumulate(rtx_scene* scene, const rtx_camera* cam, const rtx_ren
 int rtx_film_resolve(const rtx_film* film, const rtx_camera* cam, float* linear_rgb, unsigned char* rgb8,
                      float* z, int* samples, float* albedo, float* normal);
 
+/* Per-pixel running statistics of the adaptive sampler (RayCaster.cpp:832-838): device buffers of width*height
+ * float4: sum = {sum r, g, b, bits(n)}, sum2 = {sum r^2, g^2, b^2, running z}. All-zero is the empty state. */
+typedef struct {
+    float* sum;
+    float* sum2;
+} rtx_pixel_stats;
+
+/* One sampling round of RenderBucket (RayCaster.cpp:770-840, :896-956) on an explicit pixel list: samples
+ * [sample_base, sample_base + n_samples) of every listed pixel (index y*width+x, host array, any order) are traced
+ * and splatted into `film`, and the pixels' statistics are updated. reset_z restarts the running z as the reference
+ * does when refinement begins (:905). Building blocks of (a) multi-GPU adaptive sampling with per-round
+ * re-balancing of tiles (raytracer_amd/distributed.py) and (b) progressive 1-spp passes
+ * (RenderProgressiveBucket, RayCaster.cpp:1025-1144). params->spp_min/spp_max/rank/world are ignored. */
+int rtx_render_round(rtx_scene* scene, const rtx_camera* cam, const rtx_render_params* params, rtx_photons* photons,
+                     const rtx_film* film, const rtx_pixel_stats* stats, const int* pixels, size_t n_pixels, int sample_base,
+                     int n_samples, int reset_z, rtx_stats* out_stats);
+
+/* The confidence-interval test of RayCaster.cpp:848-868 over the whole frame: pixels (ascending y*width+x) with
+ * 1 < n < spp_max whose half-width exceeds ci_halfwidth. Returns their number; writes up to `capacity` of them. */
+int64_t rtx_refine_list(const rtx_pixel_stats* stats, int width, int height, float ci_halfwidth, int spp_max, int* out_pixels,
+                        size_t capacity);
+
 /* Replaces: RayCaster::Stop (RayCaster.cpp:1316-1318): asks an in-flight rtx_render* call on this scene (running in
  * another thread) to stop after the current bounce; that call returns RTX_OK with the samples accumulated so far.
  * The flag is cleared when the next render call starts. Async-safe. */

@@ -84,6 +84,10 @@ class Film(C.Structure):
                 ("normal", C.c_void_p)]
 
 
+class PixelStats(C.Structure):
+    _fields_ = [("sum", C.c_void_p), ("sum2", C.c_void_p)]
+
+
 class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_bounce", C.c_uint64), ("rays_shadow", C.c_uint64),
                 ("rays_photon", C.c_uint64), ("paths", C.c_uint64), ("nodes_visited", C.c_uint64),
@@ -135,6 +139,9 @@ SYMBOLS = [
     ("rtx_render_accumulate", C.c_int, [_vp, C.POINTER(Camera), C.POINTER(RenderParams), _vp, C.POINTER(Film),
                                         C.POINTER(Stats)]),
     ("rtx_film_resolve", C.c_int, [C.POINTER(Film), C.POINTER(Camera), _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("rtx_render_round", C.c_int, [_vp, C.POINTER(Camera), C.POINTER(RenderParams), _vp, C.POINTER(Film), C.POINTER(PixelStats),
+                                   c_int_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)]),
+    ("rtx_refine_list", C.c_int64, [C.POINTER(PixelStats), C.c_int, C.c_int, C.c_float, C.c_int, c_int_p, C.c_size_t]),
     ("rtx_cancel", C.c_int, [_vp]),
     ("rtx_render", C.c_int, [_vp, C.POINTER(Camera), C.POINTER(RenderParams), _vp, _vp, _vp, _vp, _vp,
                              C.POINTER(Stats)]),

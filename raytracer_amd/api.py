@@ -115,6 +115,16 @@ class Scene:
                                                         photons.h if photons else None, C.byref(film), C.byref(st)))
         return stats_dict(st)
 
+    def render_round(self, cam, params, film, pstats, pixels, sample_base, n_samples, reset_z=False, photons=None):
+        """rtx_render_round: samples [sample_base, sample_base+n_samples) of the listed pixels (int32 array of y*W+x)."""
+        pixels = np.ascontiguousarray(pixels, dtype=np.int32)
+        st = _ffi.Stats()
+        _check(self.lib, self.lib.rtx_render_round(self.h, C.byref(cam), C.byref(params), photons.h if photons else None,
+                                                   C.byref(film), C.byref(pstats), pixels.ctypes.data_as(_ffi.c_int_p),
+                                                   pixels.shape[0], int(sample_base), int(n_samples), int(bool(reset_z)),
+                                                   C.byref(st)))
+        return stats_dict(st)
+
     def render_samples(self, cam, params, photons=None):
         """Per-sample radiance for a fixed spp: array (H, W, spp, 4) = r, g, b, primaryDist."""
         spp = params.spp_min
@@ -127,6 +137,28 @@ class Scene:
 
 def stats_dict(st):
     return {k: getattr(st, k) for k, _ in _ffi.Stats._fields_}
+
+
+def refine_list(pstats, width, height, ci_halfwidth, spp_max):
+    """rtx_refine_list: ascending indices of the pixels whose confidence interval is still too wide."""
+    lib = _ffi.load_library()
+    out = np.empty(width * height, dtype=np.int32)
+    n = lib.rtx_refine_list(C.byref(pstats), width, height, float(ci_halfwidth), int(spp_max),
+                            out.ctypes.data_as(_ffi.c_int_p), out.shape[0])
+    if n < 0:
+        _check(lib, int(n))
+    return out[:n].copy()
+
+
+def pixel_list(width, height, tile, rank, world):
+    """Pixels of the 16x16 buckets that belong to `rank` (bucket b -> rank b % world), without padding."""
+    lib = _ffi.load_library()
+    n = lib.rtx_debug_pixel_list(width, height, tile, rank, world, None, 0)
+    if n < 0:
+        _check(lib, int(n))
+    out = np.empty(n, dtype=np.int32)
+    lib.rtx_debug_pixel_list(width, height, tile, rank, world, out.ctypes.data, out.shape[0])
+    return out[out >= 0]
 
 
 def film_clear(film, width, height, stream=None):

@@ -553,7 +553,7 @@ __global__ void film_kernel(PathPool pool, rtx_film film, const int* __restrict_
     float4 s1 = pool.statSum[pix];
     float4 s2 = pool.statSum2[pix];
     int n = __float_as_int(s1.w);
-    float bestZ = resetZ ? RTX_BIG : s2.w;
+    float bestZ = (resetZ || n == 0) ? RTX_BIG : s2.w;   // zero-filled statistics are a valid start
     const float radius = filter_radius(filterType, filterRadius);
     int cnt = film.count[pix];
     bool guide = film.albedo ? (film.albedo[4 * (size_t)pix + 3] != 0.0f) : true;
@@ -665,7 +665,7 @@ __global__ void adaptive_kernel(PathPool pool, const int* __restrict__ pixels, u
     bool refine = false;
     int pix = -1;
     if (i < nPix) {
-        pix = pixels[i];
+        pix = pixels ? pixels[i] : (int)i;   // no list: the whole frame
         if (pix >= 0) {
             const float4 s1 = pool.statSum[pix], s2 = pool.statSum2[pix];
             const int n = __float_as_int(s1.w);

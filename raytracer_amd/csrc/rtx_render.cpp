@@ -166,11 +166,22 @@ struct PassTimers {
     }
 };
 
+// One explicit round on a caller-given pixel list (rtx_render_round): samples [sampleBase, sampleBase + nSamples) of
+// every listed pixel, per-pixel statistics kept in caller-owned device buffers, no confidence-interval step.
+struct RoundSpec {
+    const int* pixels;
+    size_t nPixels;
+    int sampleBase, nSamples, resetZ;
+    float4* statSum;
+    float4* statSum2;
+};
+
 static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_params* rp, rtx_photons* photons, const rtx_film* film,
-                       rtx_stats* stats, float4* samplesOut) {
+                       rtx_stats* stats, float4* samplesOut, const RoundSpec* spec = nullptr) {
     if (!s || !cam || !rp || !film) return rtx_fail(RTX_ERR_INVALID, "NULL argument");
     if (!film->accum || !film->count || !film->z) return rtx_fail(RTX_ERR_INVALID, "film.accum/count/z must be device buffers");
-    if (rp->spp_min < 1 || rp->spp_max < rp->spp_min) return rtx_fail(RTX_ERR_INVALID, "need 1 <= spp_min <= spp_max");
+    if (!spec && (rp->spp_min < 1 || rp->spp_max < rp->spp_min)) return rtx_fail(RTX_ERR_INVALID, "need 1 <= spp_min <= spp_max");
+    if (spec && (spec->nSamples < 1 || spec->sampleBase < 0)) return rtx_fail(RTX_ERR_INVALID, "need n_samples >= 1, sample_base >= 0");
     if (rp->max_bounces < 1) return rtx_fail(RTX_ERR_INVALID, "max_bounces must be >= 1");
     const int world = rp->world > 0 ? rp->world : 1;
     if (rp->rank < 0 || rp->rank >= world) return rtx_fail(RTX_ERR_INVALID, "rank out of range");
@@ -179,14 +190,24 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     if ((rc = make_dev_camera(cam, dc)) != RTX_OK) return rc;
     const int W = dc.W, H = dc.H;
     const int stride = rp->index_stride > 0 ? rp->index_stride : 1024;
-    if ((long long)W * H * stride + rp->spp_max + 1 > 2147483647LL)
+    const int sppMax = spec ? spec->sampleBase + spec->nSamples : rp->spp_max;
+    const int perRound = spec ? spec->nSamples : rp->spp_min;
+    if ((long long)W * H * stride + sppMax + 1 > 2147483647LL)
         return rtx_fail(RTX_ERR_TOO_LARGE, "sampleIndex = (y*W+x)*index_stride+s+1 overflows int (RayCaster.cpp:784)");
-    if (rp->spp_max > stride) return rtx_fail(RTX_ERR_INVALID, "spp_max exceeds index_stride");
+    if (sppMax > stride) return rtx_fail(RTX_ERR_INVALID, "spp_max exceeds index_stride");
     const int bs = rp->tile_size > 0 ? rp->tile_size : 16;
 
     std::vector<int> list;
     size_t nValid = 0;
-    build_pixel_list(W, H, bs, rp->rank, world, list, nValid);
+    if (spec) {
+        if (spec->nPixels && !spec->pixels) return rtx_fail(RTX_ERR_INVALID, "pixel list is NULL");
+        list.assign(spec->pixels, spec->pixels + spec->nPixels);
+        for (int p : list)
+            if (p < 0 || p >= W * H) return rtx_fail(RTX_ERR_INVALID, "pixel index outside the frame");
+        nValid = list.size();
+        list.resize((list.size() + 63) & ~(size_t)63, -1);   // whole waves
+    } else
+        build_pixel_list(W, H, bs, rp->rank, world, list, nValid);
     uint32_t nPix = (uint32_t)list.size();
 
     DevPhotonMap pm;
@@ -204,9 +225,9 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
         const size_t perSlot = 192 + 48 * (size_t)std::max(1, s->dev.n_lights);
         const size_t budget = std::min<size_t>((size_t)(0.4 * (double)freeB), (size_t)96 << 30);
         const size_t target = std::max<size_t>(budget / perSlot, 1u << 20);
-        S = (int)std::max<size_t>(1, std::min<size_t>((size_t)rp->spp_min, target / std::max<uint32_t>(nPix, 1)));
+        S = (int)std::max<size_t>(1, std::min<size_t>((size_t)perRound, target / std::max<uint32_t>(nPix, 1)));
     }
-    S = std::min(S, rp->spp_min);
+    S = std::min(S, perRound);
     // slot * 8 + light must fit 32 bits (shadow queue entries)
     while (S > 1 && (size_t)nPix * S > 0x1FFFFFFFull) --S;
     if ((size_t)nPix * S > 0x1FFFFFFFull) return rtx_fail(RTX_ERR_TOO_LARGE, "more than 2^29 path slots per pass");
@@ -216,7 +237,11 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
         return rtx_fail(RTX_ERR_TOO_LARGE, "more than 2^32 shadow segments per pass");
     if ((rc = ensure_pool(s, nPix * (uint32_t)S, (size_t)W * H, nPix, usePhotons)) != RTX_OK) return rc;
     PathPoolHost* ph = reinterpret_cast<PathPoolHost*>(s->pool);
-    PathPool& pool = ph->dev;
+    PathPool pool = ph->dev;
+    if (spec) {
+        pool.statSum = spec->statSum;
+        pool.statSum2 = spec->statSum2;
+    }
     hipStream_t st = s->cfg.stream;
 
     rtx_stats out;
@@ -227,7 +252,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     RTX_HIP(hipEventRecord(evTotal0, st));
 
     if (nPix) RTX_HIP(hipMemcpyAsync(pool.pixels, list.data(), (size_t)nPix * sizeof(int), hipMemcpyHostToDevice, st));
-    launch_stats_clear(pool, (uint32_t)((size_t)W * H), st);
+    if (!spec) launch_stats_clear(pool, (uint32_t)((size_t)W * H), st);
     RTX_HIP(hipMemsetAsync(pool.rayCounters, 0, 8 * sizeof(unsigned long long), st));
     if (s->cfg.counting) RTX_HIP(hipMemsetAsync(s->cfg.counters, 0, 3 * sizeof(unsigned long long), st));
     // queue counters are left at zero by every scan; a cancelled or failed call may have left some behind
@@ -241,9 +266,9 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     int* curPixels = pool.pixels;
     int* nextPixels = pool.pixelsNext;
     size_t curValid = nValid;
-    int roundBase = 0;
+    int roundBase = spec ? spec->sampleBase : 0;
     for (int round = 0; nPix > 0 && curValid > 0; ++round) {
-        const int target = std::min(rp->spp_min, rp->spp_max - roundBase);
+        const int target = std::min(perRound, sppMax - roundBase);
         if (target <= 0) break;
         for (int done = 0; done < target && !s->cancel.load(std::memory_order_relaxed);) {
             const int Sp = std::min(S, target - done);
@@ -287,13 +312,13 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
             }
             // a pass interrupted by rtx_cancel holds unfinished paths: it is dropped, earlier passes stay
             if (!s->cancel.load(std::memory_order_relaxed))
-                launch_film(pool, *film, curPixels, nPix, Sp, W, H, rp->filter_type, rp->filter_radius, (round == 1 && done == 0) ? 1 : 0,
-                        samplesOut, sBase, rp->spp_max, st);
+                launch_film(pool, *film, curPixels, nPix, Sp, W, H, rp->filter_type, rp->filter_radius,
+                            (done == 0 && (spec ? spec->resetZ != 0 : round == 1)) ? 1 : 0, samplesOut, sBase, sppMax, st);
             done += Sp;
         }
         roundBase += target;
         if (s->cancel.load(std::memory_order_relaxed)) break;
-        if (rp->spp_max <= rp->spp_min || roundBase >= rp->spp_max) break;
+        if (spec || rp->spp_max <= rp->spp_min || roundBase >= rp->spp_max) break;
         // ---- confidence-interval test -> next pixel list ----
         launch_fill_int(nextPixels, nPix, -1, st);
         RTX_HIP(hipMemsetAsync(pool.counters + 8, 0, sizeof(uint32_t), st));
@@ -336,6 +361,43 @@ int rtx_cancel(rtx_scene* s) {
     if (!s) return rtx_fail(RTX_ERR_INVALID, "scene is NULL");
     s->cancel.store(1);
     return RTX_OK;
+}
+
+int rtx_render_round(rtx_scene* s, const rtx_camera* cam, const rtx_render_params* rp, rtx_photons* photons, const rtx_film* film,
+                     const rtx_pixel_stats* st, const int* pixels, size_t n_pixels, int sample_base, int n_samples, int reset_z,
+                     rtx_stats* stats) {
+    if (!st || !st->sum || !st->sum2) return rtx_fail(RTX_ERR_INVALID, "pixel statistics buffers are NULL");
+    RoundSpec spec{pixels, n_pixels, sample_base, n_samples, reset_z, (float4*)st->sum, (float4*)st->sum2};
+    return render_impl(s, cam, rp, photons, film, stats, nullptr, &spec);
+}
+
+int64_t rtx_refine_list(const rtx_pixel_stats* st, int width, int height, float ci_halfwidth, int spp_max, int* out_pixels,
+                        size_t capacity) {
+    if (!st || !st->sum || !st->sum2 || width <= 0 || height <= 0) return rtx_fail(RTX_ERR_INVALID, "bad argument");
+    if (rtx_device_count() <= 0) return rtx_fail(RTX_ERR_NO_DEVICE, "no HIP device present");
+    const uint32_t n = (uint32_t)((size_t)width * height);
+    int* dList = nullptr;
+    uint32_t* dCount = nullptr;
+    RTX_HIP(hipMalloc((void**)&dList, (size_t)n * sizeof(int)));
+    if (hipMalloc((void**)&dCount, sizeof(uint32_t)) != hipSuccess) {
+        (void)hipFree(dList);
+        return rtx_fail(RTX_ERR_HIP, "hipMalloc failed");
+    }
+    (void)hipMemset(dCount, 0, sizeof(uint32_t));
+    PathPool view{};
+    view.statSum = (float4*)st->sum;
+    view.statSum2 = (float4*)st->sum2;
+    launch_adaptive(view, nullptr, n, ci_halfwidth, spp_max, dList, dCount, nullptr);
+    uint32_t cnt = 0;
+    hipError_t e = hipMemcpy(&cnt, dCount, sizeof(cnt), hipMemcpyDeviceToHost);
+    std::vector<int> host(cnt);
+    if (e == hipSuccess && cnt) e = hipMemcpy(host.data(), dList, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipFree(dList);
+    (void)hipFree(dCount);
+    if (e != hipSuccess) return rtx_fail(RTX_ERR_HIP, std::string("refine list: ") + hipGetErrorString(e));
+    std::sort(host.begin(), host.end());   // the compaction order depends on wave scheduling; ranks must agree
+    if (out_pixels) std::memcpy(out_pixels, host.data(), std::min(capacity, (size_t)cnt) * sizeof(int));
+    return (int64_t)cnt;
 }
 
 int rtx_film_clear(const rtx_film* film, int width, int height, void* stream) {

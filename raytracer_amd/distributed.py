@@ -5,6 +5,8 @@ sample counts, min of z). Ranks do the same across GPUs with torch.distributed (
 ROCm; "gloo" in the CPU tests). Samples splat into neighbouring pixels (tent radius 1, RayCaster.cpp:810-829), so the
 exchange must be a sum-reduce of full-frame films, not a gather of disjoint tiles.
 """
+import numpy as np
+import torch
 import torch.distributed as dist
 
 
@@ -20,3 +22,93 @@ def reduce_film(accum, count, z, dst=0, group=None):
 def photon_split(rank, world):
     """Photon ids of a rank: rank, rank + world, ... (PhotonMapBuilder.cpp:110 hands ids out one by one)."""
     return dict(first_photon=rank, photon_stride=world)
+
+
+# ---- adaptive sampling across GPUs (SURVEY.md 8e, config C4) -----------------------------------------------------
+# Round 1 (spp_min samples everywhere) uses the static round-robin bucket split. After every round the ranks share
+# the per-pixel statistics of the pixels they just sampled, run the same confidence-interval test
+# (RayCaster.cpp:848-868) and deal the buckets that still hold unconverged pixels out again, heaviest first, to the
+# least loaded rank (greedy LPT). Migrating a bucket costs nothing beyond that exchange: its accumulated colour
+# stays in the film of whichever rank produced it (films are summed at frame end), only the statistics move.
+
+
+def bucket_of_pixels(pixels, width, height, tile=16):
+    """Bucket index (row-major over ceil(W/tile) x ceil(H/tile), RayCaster.cpp:1152-1158) of pixel indices y*W+x."""
+    pixels = np.asarray(pixels, dtype=np.int64)
+    nbx = (width + tile - 1) // tile
+    return ((pixels // width) // tile) * nbx + (pixels % width) // tile
+
+
+def lpt_assign(weights, world):
+    """Greedy longest-processing-time assignment. weights: array of per-bucket work (0 = nothing to do).
+    Returns owner[bucket] in [0, world) for buckets with work and -1 otherwise. Deterministic: buckets by decreasing
+    weight then increasing index, ties between ranks to the lowest rank."""
+    weights = np.asarray(weights, dtype=np.int64)
+    owner = np.full(weights.shape[0], -1, dtype=np.int32)
+    load = np.zeros(world, dtype=np.int64)
+    busy = np.nonzero(weights > 0)[0]
+    order = busy[np.lexsort((busy, -weights[busy]))]
+    for b in order:
+        r = int(np.argmin(load))
+        owner[b] = r
+        load[r] += weights[b]
+    return owner
+
+
+def _all_reduce_exact(t, group=None):
+    """SUM all-reduce of bit patterns (int32 view): exact when at most one rank holds a non-zero value per element."""
+    v = t.view(torch.int32)
+    if dist.get_backend(group) == "gloo" and v.is_cuda:
+        h = v.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        v.copy_(h)
+    else:
+        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+
+
+def render_adaptive(scene, cam, params, film, pstats, stat_sum, stat_sum2, rank=0, world=1, group=None, photons=None,
+                    tile=16):
+    """Adaptive CastRays (spp_min ... spp_max, RayCaster.cpp:770-980) on `world` GPUs with per-round LPT re-balancing.
+
+    scene: raytracer_amd.Scene; film: _ffi.Film over this rank's device buffers (cleared by the caller);
+    pstats: _ffi.PixelStats over stat_sum / stat_sum2 (zero-filled float32 [W*H, 4] device tensors).
+    Returns a list with one dict per round: pixels sampled by this rank, by all ranks, samples per pixel."""
+    from . import api
+    W, H = cam.width, cam.height
+    spp_min, spp_max = params.spp_min, params.spp_max
+    multi = world > 1 and dist.is_initialized()
+    mine = api.pixel_list(W, H, tile, rank, world)
+    everyone = None            # pixels sampled in the round just finished, over all ranks (None = the whole frame)
+    base, rounds = 0, []
+    while True:
+        n = min(spp_min, spp_max - base)
+        if n <= 0:
+            break
+        scene.render_round(cam, params, film, pstats, mine, base, n, reset_z=(len(rounds) == 1), photons=photons)
+        rounds.append(dict(mine=int(mine.shape[0]), total=int(W * H if everyone is None else everyone.shape[0]), samples=n))
+        base += n
+        if spp_max <= spp_min or base >= spp_max:
+            break
+        if multi:
+            # statistics of the pixels this rank just sampled -> every rank
+            for t in (stat_sum, stat_sum2):
+                contrib = torch.zeros_like(t)
+                if mine.shape[0]:
+                    idx = torch.from_numpy(mine.astype(np.int64)).to(t.device)
+                    contrib[idx] = t[idx]
+                _all_reduce_exact(contrib, group)
+                if everyone is None:
+                    t.copy_(contrib)
+                else:
+                    idx = torch.from_numpy(everyone.astype(np.int64)).to(t.device)
+                    t[idx] = contrib[idx]
+            torch.cuda.synchronize()
+        refine = api.refine_list(pstats, W, H, params.ci_halfwidth, spp_max)
+        if refine.shape[0] == 0:
+            break
+        buckets = bucket_of_pixels(refine, W, H, tile)
+        nb = ((W + tile - 1) // tile) * ((H + tile - 1) // tile)
+        owner = lpt_assign(np.bincount(buckets, minlength=nb), world)
+        mine = refine[owner[buckets] == rank]
+        everyone = refine
+    return rounds

@@ -63,3 +63,31 @@ def test_two_rank_film_reduce_equals_single_rank(tmp_path):
     assert np.allclose(got["accum"], ref["accum"].reshape(n, 4), rtol=1e-5, atol=1e-6)   # float sum order only
     ph = OraclePhotons(osc, 20000, finalize=False)
     assert got["cnt"][0] == ph.info()["n_global"] and got["cnt"][1] == ph.info()["n_caustic"]
+
+
+def test_lpt_assignment_is_balanced_and_deterministic():
+    """raytracer_amd.distributed.lpt_assign / bucket_of_pixels: the host logic of the per-round re-balancing (8e)."""
+    from raytracer_amd.distributed import lpt_assign, bucket_of_pixels
+    from raytracer_amd import api
+    rng = np.random.default_rng(3)
+    w = rng.integers(0, 257, 8160)
+    w[rng.random(8160) < 0.6] = 0                      # most buckets converge after round 1
+    for world in (1, 2, 4, 8):
+        owner = lpt_assign(w, world)
+        assert ((owner >= 0) == (w > 0)).all() and owner.max() < world
+        load = np.bincount(owner[owner >= 0], weights=w[owner >= 0], minlength=world)
+        assert load.max() - load.min() <= w.max()      # greedy LPT bound
+        assert np.array_equal(owner, lpt_assign(w.copy(), world))
+    # a clustered load that the static b % world split handles badly
+    w2 = np.zeros(8160, np.int64)
+    w2[0:400:8] = 256
+    static = np.bincount(np.arange(8160)[w2 > 0] % 8, weights=w2[w2 > 0], minlength=8)
+    lpt = np.bincount(lpt_assign(w2, 8)[w2 > 0], weights=w2[w2 > 0], minlength=8)
+    assert static.max() == w2.sum() and lpt.max() <= w2.sum() / 8 + 256
+    # bucket ids agree with the library's bucket order
+    W, H = 100, 70
+    for rank in range(3):
+        px = api.pixel_list(W, H, 16, rank, 3)
+        assert (bucket_of_pixels(px, W, H, 16) % 3 == rank).all()
+    allpx = np.sort(np.concatenate([api.pixel_list(W, H, 16, r, 3) for r in range(3)]))
+    assert np.array_equal(allpx, np.arange(W * H))
