@@ -280,6 +280,11 @@ typedef struct {
     float* sum2;
 } rtx_pixel_stats;
 
+/* Film and statistics buffers owned by the library, for hosts that do not manage device memory themselves (the C++
+ * mirror of RayCaster's progressive mode). Cleared on creation; albedo/normal guides included. */
+int rtx_film_create(int width, int height, rtx_film* film, rtx_pixel_stats* stats);
+void rtx_film_destroy(rtx_film* film, rtx_pixel_stats* stats);
+
 /* One sampling round of RenderBucket (RayCaster.cpp:770-840, :896-956) on an explicit pixel list: samples
  * [sample_base, sample_base + n_samples) of every listed pixel (index y*width+x, host array, any order) are traced
  * and splatted into `film`, and the pixels' statistics are updated. reset_z restarts the running z as the reference

@@ -139,6 +139,8 @@ SYMBOLS = [
     ("rtx_render_accumulate", C.c_int, [_vp, C.POINTER(Camera), C.POINTER(RenderParams), _vp, C.POINTER(Film),
                                         C.POINTER(Stats)]),
     ("rtx_film_resolve", C.c_int, [C.POINTER(Film), C.POINTER(Camera), _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("rtx_film_create", C.c_int, [C.c_int, C.c_int, C.POINTER(Film), C.POINTER(PixelStats)]),
+    ("rtx_film_destroy", None, [C.POINTER(Film), C.POINTER(PixelStats)]),
     ("rtx_render_round", C.c_int, [_vp, C.POINTER(Camera), C.POINTER(RenderParams), _vp, C.POINTER(Film), C.POINTER(PixelStats),
                                    c_int_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)]),
     ("rtx_refine_list", C.c_int64, [C.POINTER(PixelStats), C.c_int, C.c_int, C.c_float, C.c_int, c_int_p, C.c_size_t]),

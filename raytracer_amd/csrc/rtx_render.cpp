@@ -473,6 +473,42 @@ static int alloc_film(size_t n, rtx_film& f, std::vector<void*>& owned) {
     return RTX_OK;
 }
 
+int rtx_film_create(int width, int height, rtx_film* film, rtx_pixel_stats* stats) {
+    if (!film || !stats || width <= 0 || height <= 0) return rtx_fail(RTX_ERR_INVALID, "bad argument");
+    if (rtx_device_count() <= 0) return rtx_fail(RTX_ERR_NO_DEVICE, "no HIP device present");
+    const size_t n = (size_t)width * height;
+    std::vector<void*> owned;
+    int rc = alloc_film(n, *film, owned);
+    if (rc != RTX_OK) return rc;
+    stats->sum = stats->sum2 = nullptr;
+    if (hipMalloc((void**)&stats->sum, n * 16) != hipSuccess || hipMalloc((void**)&stats->sum2, n * 16) != hipSuccess) {
+        rtx_film_destroy(film, stats);
+        return rtx_fail(RTX_ERR_HIP, "statistics allocation failed");
+    }
+    hipError_t e = hipMemset(stats->sum, 0, n * 16);
+    if (e == hipSuccess) e = hipMemset(stats->sum2, 0, n * 16);
+    if (e != hipSuccess) {
+        rtx_film_destroy(film, stats);
+        return rtx_fail(RTX_ERR_HIP, "statistics clear failed");
+    }
+    if ((rc = rtx_film_clear(film, width, height, nullptr)) != RTX_OK) rtx_film_destroy(film, stats);
+    return rc;
+}
+
+void rtx_film_destroy(rtx_film* film, rtx_pixel_stats* stats) {
+    if (film) {
+        void* p[5] = {film->accum, film->count, film->z, film->albedo, film->normal};
+        for (void* q : p)
+            if (q) (void)hipFree(q);
+        *film = rtx_film{};
+    }
+    if (stats) {
+        if (stats->sum) (void)hipFree(stats->sum);
+        if (stats->sum2) (void)hipFree(stats->sum2);
+        stats->sum = stats->sum2 = nullptr;
+    }
+}
+
 int rtx_render(rtx_scene* s, const rtx_camera* cam, const rtx_render_params* rp, rtx_photons* photons, float* linear_rgb,
                unsigned char* rgb8, float* z, int* samples, rtx_stats* stats) {
     if (!s || !cam) return rtx_fail(RTX_ERR_INVALID, "NULL argument");

@@ -29,6 +29,7 @@ struct SamplingConfig {
     uint64_t seed = 0x9e3779b97f4a7c15ULL;
     int rank = 0, world = 1;          // tile sharding across GPUs (one process per GPU)
     int samplesPerPass = 0;           // samples per pixel in flight at once; 0 = sized from free HBM
+    int progressiveSamplesPerPass = 1;   // kProgressiveSamplesPerPass, RayCaster.cpp:62
 };
 
 class RayCaster {
@@ -67,6 +68,11 @@ public:
         rtx_photons* ph = photonMapper ? photonMapper->Handle() : nullptr;
         rp.use_photons = ph ? 1 : 0;
         active = gs.Handle();
+        if (progressivePreview) {
+            CastRaysProgressive(image, gs.Handle(), cam, rp, ph);
+            active = nullptr;
+            return;
+        }
         static_assert(sizeof(Color) == 12 && sizeof(Color24) == 3, "RenderImage arrays must be tightly packed");
         int rc = rtx_render(gs.Handle(), &cam, &rp, ph, &image.GetLinearPixels()->r, &image.GetPixels()->r, image.GetZBuffer(),
                             image.GetSampleCount(), &lastStats);
@@ -76,6 +82,65 @@ public:
             return;
         }
         image.IncrementNumRenderPixel(W * H);
+    }
+    // Progressive mode (RayCaster.cpp:1025-1144, 1215-1279): batches of one eighth of the buckets take
+    // kProgressiveSamplesPerPass samples per pixel per visit, the image is refreshed after every batch, and the loop
+    // ends when every pixel holds maxSamples (no confidence-interval test) or Stop() is called.
+    void CastRaysProgressive(RenderImage& image, rtx_scene* gpu, const rtx_camera& cam, const rtx_render_params& rp, rtx_photons* ph) {
+        const int W = cam.width, H = cam.height, bs = 16;
+        rtx_film film{};
+        rtx_pixel_stats pst{};
+        if (rtx_film_create(W, H, &film, &pst) != RTX_OK) {
+            std::cerr << "CastRays failed: " << rtx_last_error() << "\n";
+            return;
+        }
+        std::vector<Bucket> buckets;   // RayCaster.cpp:1152-1158
+        for (int y = 0; y < H; y += bs)
+            for (int x = 0; x < W; x += bs) buckets.push_back(Bucket{x, y, std::min(x + bs, W), std::min(y + bs, H)});
+        std::vector<int> taken(buckets.size(), 0);
+        const size_t batchSize = std::max<size_t>(1, buckets.size() / 8);
+        const int perPass = std::max(1, sampling.progressiveSamplesPerPass);
+        size_t cursor = 0;
+        bool allDone = false, seeded = false;
+        image.ResetNumRenderedPixels();
+        std::vector<int> pixels;
+        while (!stopFlag && !allDone) {
+            const size_t batchEnd = std::min(cursor + batchSize, buckets.size());
+            // buckets of a batch that hold the same number of samples go into one round
+            for (size_t b = cursor; b < batchEnd && !stopFlag;) {
+                const int base = taken[b];
+                pixels.clear();
+                size_t e = b;
+                for (; e < batchEnd && taken[e] == base; ++e)
+                    for (int y = buckets[e].y0; y < buckets[e].y1; ++y)
+                        for (int x = buckets[e].x0; x < buckets[e].x1; ++x) pixels.push_back(y * W + x);
+                const int n = std::min(perPass, sampling.maxSamples - base);
+                if (n > 0) {
+                    if (rtx_render_round(gpu, &cam, &rp, ph, &film, &pst, pixels.data(), pixels.size(), base, n, 1, &lastStats) != RTX_OK) {
+                        std::cerr << "CastRays failed: " << rtx_last_error() << "\n";
+                        rtx_film_destroy(&film, &pst);
+                        return;
+                    }
+                    for (size_t k = b; k < e; ++k) taken[k] = base + n;
+                }
+                b = e;
+            }
+            // mergeToImage
+            if (rtx_film_resolve(&film, &cam, &image.GetLinearPixels()->r, &image.GetPixels()->r, image.GetZBuffer(),
+                                 image.GetSampleCount(), nullptr, nullptr) != RTX_OK)
+                std::cerr << "CastRays failed: " << rtx_last_error() << "\n";
+            image.IncrementNumRenderPixel(seeded ? 1 : W * H);
+            seeded = true;
+            if (stopFlag) break;
+            allDone = true;
+            for (int t : taken)
+                if (t < sampling.maxSamples) {
+                    allDone = false;
+                    break;
+                }
+            cursor = batchEnd >= buckets.size() ? 0 : batchEnd;
+        }
+        rtx_film_destroy(&film, &pst);
     }
     void Stop() {
         stopFlag = true;

@@ -275,6 +275,26 @@ int main() {
     img2.Init(cam.imgWidth, cam.imgHeight);
     rc.CastRays(img2, &pmb);
 
+    // progressive preview (RayCaster.cpp:1215-1279): 1-spp visits of bucket batches until every pixel holds maxSamples;
+    // the same samples as the fixed 8-spp frame above, so the same image up to the order of the film's float atomics
+    {
+        RayCaster rcp(&scene, &cam);
+        rcp.sampling.minSamples = rcp.sampling.maxSamples = 8;
+        rcp.sampling.maxBounces = rc.sampling.maxBounces;
+        rcp.SetProgressivePreview(true);
+        RenderImage imgP;
+        imgP.Init(cam.imgWidth, cam.imgHeight);
+        rcp.CastRays(imgP);
+        int badCount = 0, badPix = 0;
+        for (size_t i = 0; i < np; ++i) {
+            if (imgP.GetSampleCount()[i] != 8) ++badCount;
+            const Color a = imgP.GetLinearPixels()[i], b = img.GetLinearPixels()[i];
+            if (std::fabs(a.r - b.r) > 2e-4f * (1 + b.r) || std::fabs(a.g - b.g) > 2e-4f * (1 + b.g) || std::fabs(a.b - b.b) > 2e-4f * (1 + b.b)) ++badPix;
+        }
+        CHECK(badCount == 0 && badPix == 0, "progressive preview: %d sample counts off, %d pixels differ", badCount, badPix);
+        CHECK(imgP.GetNumRenderedPixels() >= (int)np, "progressive preview advances the rendered-pixel counter");
+    }
+
     // Stop() from another thread ends a long render early
     rc.sampling.minSamples = rc.sampling.maxSamples = 1024;
     rc.sampling.samplesPerPass = 2;   // 512 passes, so the render outlasts the stopper's delay on any GPU
