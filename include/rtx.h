@@ -280,6 +280,12 @@ typedef struct {
     float* sum2;
 } rtx_pixel_stats;
 
+/* Replaces: Denoiser::ApplyMedian / MedianFilterToLinear (Denoiser.cpp:19-134): 3x3 median per channel with the
+ * window clamped to the image, then clamp to [0,1], optional Linear2sRGB and truncation to 8 bits. Host arrays:
+ * linear_rgb_in width*height*3; outputs optional (linear_rgb_out width*height*3, rgb8_out width*height*3). */
+int rtx_median_denoise(const float* linear_rgb_in, int width, int height, int srgb, float* linear_rgb_out,
+                       unsigned char* rgb8_out);
+
 /* Film and statistics buffers owned by the library, for hosts that do not manage device memory themselves (the C++
  * mirror of RayCaster's progressive mode). Cleared on creation; albedo/normal guides included. */
 int rtx_film_create(int width, int height, rtx_film* film, rtx_pixel_stats* stats);

@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE ONLY (see oracle_math.h). C entry points of the CPU restatement, loaded with ctypes by
 // tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by the product.
 #include "oracle_shade.h"
+#include <algorithm>
 #include <cstring>
 #include <chrono>
 
@@ -221,6 +222,35 @@ int orc_film_resolve(const float* accum, int W, int H, int srgb, float* linear, 
         if (linear) { linear[3 * i] = fin.x; linear[3 * i + 1] = fin.y; linear[3 * i + 2] = fin.z; }
         if (rgb8) to_color24(fin, srgb != 0, rgb8 + 3 * i);
     }
+    return 0;
+}
+
+// Denoiser.cpp:19-134: 3x3 median per channel (window clamped to the image), then ToColor24-style conversion
+int orc_median_denoise(const float* in, int W, int H, int srgb, float* linear, unsigned char* rgb8) {
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            float buf[3][9];
+            int count = 0;
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = std::min(std::max(y + dy, 0), H - 1);
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int xx = std::min(std::max(x + dx, 0), W - 1);
+                    for (int c = 0; c < 3; ++c) buf[c][count] = in[3 * ((size_t)yy * W + xx) + c];
+                    ++count;
+                }
+            }
+            const size_t i = (size_t)y * W + x;
+            float m[3];
+            for (int c = 0; c < 3; ++c) {
+                std::nth_element(buf[c], buf[c] + count / 2, buf[c] + count);
+                m[c] = buf[c][count / 2];
+                if (linear) linear[3 * i + c] = m[c];
+            }
+            if (rgb8) {
+                V3 cl(std::min(std::max(m[0], 0.0f), 1.0f), std::min(std::max(m[1], 0.0f), 1.0f), std::min(std::max(m[2], 0.0f), 1.0f));
+                to_color24(cl, srgb != 0, rgb8 + 3 * i);
+            }
+        }
     return 0;
 }
 

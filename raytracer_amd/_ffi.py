@@ -139,6 +139,7 @@ SYMBOLS = [
     ("rtx_render_accumulate", C.c_int, [_vp, C.POINTER(Camera), C.POINTER(RenderParams), _vp, C.POINTER(Film),
                                         C.POINTER(Stats)]),
     ("rtx_film_resolve", C.c_int, [C.POINTER(Film), C.POINTER(Camera), _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("rtx_median_denoise", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     ("rtx_film_create", C.c_int, [C.c_int, C.c_int, C.POINTER(Film), C.POINTER(PixelStats)]),
     ("rtx_film_destroy", None, [C.POINTER(Film), C.POINTER(PixelStats)]),
     ("rtx_render_round", C.c_int, [_vp, C.POINTER(Camera), C.POINTER(RenderParams), _vp, C.POINTER(Film), C.POINTER(PixelStats),

@@ -139,6 +139,17 @@ def stats_dict(st):
     return {k: getattr(st, k) for k, _ in _ffi.Stats._fields_}
 
 
+def median_denoise(linear, srgb=False):
+    """rtx_median_denoise: 3x3 median of a linear RGB image (H, W, 3); returns (linear_out, rgb8_out)."""
+    lib = _ffi.load_library()
+    src = np.ascontiguousarray(linear, dtype=np.float32)
+    H, W = src.shape[:2]
+    lin = np.empty_like(src)
+    rgb8 = np.empty((H, W, 3), dtype=np.uint8)
+    _check(lib, lib.rtx_median_denoise(src.ctypes.data, W, H, int(bool(srgb)), lin.ctypes.data, rgb8.ctypes.data))
+    return lin, rgb8
+
+
 def refine_list(pstats, width, height, ci_halfwidth, spp_max):
     """rtx_refine_list: ascending indices of the pixels whose confidence interval is still too wide."""
     lib = _ffi.load_library()

@@ -44,6 +44,9 @@ void launch_expand_hits(const DevScene& sc, const float4* rays, const float4* hi
 void launch_visibility(const DevScene& sc, const LaunchCfg& cfg, const float4* rays, const float4* normals, uint32_t n,
                        int useTransmittance, float* vis, unsigned long long* hopCounter);
 
+// 3x3 median of a linear RGB image (device pointers; linear / rgb8 outputs optional)
+void launch_median3(const float* src, int W, int H, int srgb, float* linear, unsigned char* rgb8, hipStream_t stream);
+
 int query_resident_blocks(int which);  // blocks per CU for kernel 'which' (0 extend, 1 shadow)
 
 // ---- wavefront path tracing (kernels_path.hip) ----

@@ -473,6 +473,29 @@ static int alloc_film(size_t n, rtx_film& f, std::vector<void*>& owned) {
     return RTX_OK;
 }
 
+int rtx_median_denoise(const float* in, int width, int height, int srgb, float* linear_out, unsigned char* rgb8_out) {
+    if (!in || width <= 0 || height <= 0) return rtx_fail(RTX_ERR_INVALID, "bad argument");
+    if (rtx_device_count() <= 0) return rtx_fail(RTX_ERR_NO_DEVICE, "no HIP device present");
+    const size_t n = (size_t)width * height;
+    float *dIn = nullptr, *dLin = nullptr;
+    unsigned char* d8 = nullptr;
+    hipError_t e = hipMalloc((void**)&dIn, n * 12);
+    if (e == hipSuccess && linear_out) e = hipMalloc((void**)&dLin, n * 12);
+    if (e == hipSuccess && rgb8_out) e = hipMalloc((void**)&d8, n * 3);
+    if (e == hipSuccess) e = hipMemcpy(dIn, in, n * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch_median3(dIn, width, height, srgb, dLin, d8, nullptr);
+        e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess && linear_out) e = hipMemcpy(linear_out, dLin, n * 12, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && rgb8_out) e = hipMemcpy(rgb8_out, d8, n * 3, hipMemcpyDeviceToHost);
+    if (dIn) (void)hipFree(dIn);
+    if (dLin) (void)hipFree(dLin);
+    if (d8) (void)hipFree(d8);
+    if (e != hipSuccess) return rtx_fail(RTX_ERR_HIP, std::string("median denoise: ") + hipGetErrorString(e));
+    return RTX_OK;
+}
+
 int rtx_film_create(int width, int height, rtx_film* film, rtx_pixel_stats* stats) {
     if (!film || !stats || width <= 0 || height <= 0) return rtx_fail(RTX_ERR_INVALID, "bad argument");
     if (rtx_device_count() <= 0) return rtx_fail(RTX_ERR_NO_DEVICE, "no HIP device present");

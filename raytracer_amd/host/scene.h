@@ -14,6 +14,7 @@
 #include <utility>
 #include <vector>
 #include "../../include/rtx.h"
+#include "ImageIO.h"
 
 namespace rtamd {
 
@@ -265,6 +266,39 @@ public:
     Color* GetLinearPixels() { return linear.data(); }
     Color* GetAlbedo() { return albedo.data(); }
     Vec3f* GetNormal() { return normal.data(); }
+    // 8-bit views of the z buffer and the sample counts, as the framework's RenderImage computes them before saving
+    // (stand-in for the absent framework code: nearest = white, background (BIGFLOAT) = black; counts scaled min..max).
+    void ComputeZBufferImage() {
+        zImg.assign(zbuffer.size(), 0);
+        float zmin = BIGFLOAT, zmax = 0.0f;
+        for (float z : zbuffer) {
+            if (z == BIGFLOAT) continue;
+            zmin = std::fmin(zmin, z);
+            zmax = std::fmax(zmax, z);
+        }
+        for (size_t i = 0; i < zbuffer.size(); ++i) {
+            if (zbuffer[i] == BIGFLOAT) continue;
+            const float f = zmax > zmin ? (zmax - zbuffer[i]) / (zmax - zmin) : 1.0f;
+            int c = (int)(f * 255.0f);
+            zImg[i] = (uint8_t)(c < 0 ? 0 : (c > 255 ? 255 : c));
+        }
+    }
+    int ComputeSampleCountImage() {
+        sImg.assign(sampleCount.size(), 0);
+        int smin = 0x7FFFFFFF, smax = 0;
+        for (int s : sampleCount) {
+            smin = s < smin ? s : smin;
+            smax = s > smax ? s : smax;
+        }
+        if (smax > smin)
+            for (size_t i = 0; i < sampleCount.size(); ++i) sImg[i] = (uint8_t)((255 * (sampleCount[i] - smin)) / (smax - smin));
+        return smax;
+    }
+    uint8_t* GetZBufferImage() { return zImg.data(); }
+    uint8_t* GetSampleCountImage() { return sImg.data(); }
+    bool SaveImage(const char* filename) const { return png::save(filename, &img.data()->r, width, height, 3); }
+    bool SaveZImage(const char* filename) const { return zImg.size() == img.size() && png::save(filename, zImg.data(), width, height, 1); }
+    bool SaveSampleCountImage(const char* filename) const { return sImg.size() == img.size() && png::save(filename, sImg.data(), width, height, 1); }
     void IncrementNumRenderPixel(int n) { numRendered += n; }
     int GetNumRenderedPixels() const { return numRendered; }
     void ResetNumRenderedPixels() { numRendered = 0; }
@@ -276,6 +310,7 @@ private:
     std::vector<int> sampleCount;
     std::vector<Color> linear, albedo;
     std::vector<Vec3f> normal;
+    std::vector<uint8_t> zImg, sImg;
 };
 
 }  // namespace rtamd

@@ -9,6 +9,7 @@
 #include <thread>
 #include "../../raytracer_amd/host/RayCaster.h"
 #include "../../raytracer_amd/host/ShadeInfoAdapter.h"
+#include "../../raytracer_amd/host/Denoiser.h"
 
 using namespace rtamd;
 
@@ -18,6 +19,7 @@ void orc_scene_destroy(void* s);
 int orc_trace_closest(void* s, const rtx_ray* rays, size_t n, int hit_side, int with_lights, int use_bvh, rtx_hit* hits, uint64_t* counters);
 int orc_render(void* s, const rtx_camera* cam, const rtx_render_params* rp, void* photons, int nthreads, int subset_stride, float* accum,
                int* count, float* z, float* albedo, float* normal, float* linear, unsigned char* rgb8, uint64_t* counters, double* secs);
+int orc_median_denoise(const float* in, int W, int H, int srgb, float* linear, unsigned char* rgb8);
 }
 
 static int failures = 0;
@@ -274,6 +276,25 @@ int main() {
     RenderImage img2;
     img2.Init(cam.imgWidth, cam.imgHeight);
     rc.CastRays(img2, &pmb);
+
+    // outputs: median denoise on the GPU against the oracle, PNG files of colour / z / sample counts
+    {
+        std::vector<unsigned char> gpu8(np * 3), cpu8(np * 3);
+        std::string err;
+        CHECK(Denoiser::ApplyMedian(img, true, "/tmp/rtamd_denoised.png", reinterpret_cast<Color24*>(gpu8.data()), &err), "ApplyMedian: %s", err.c_str());
+        orc_median_denoise(&img.GetLinearPixels()->r, cam.imgWidth, cam.imgHeight, 1, nullptr, cpu8.data());
+        int off = 0;
+        for (size_t i = 0; i < np * 3; ++i) off += std::abs((int)gpu8[i] - (int)cpu8[i]) > 1;
+        CHECK(off == 0, "median denoise: %d bytes differ by more than one level", off);
+        img.ComputeZBufferImage();
+        const int smax = img.ComputeSampleCountImage();
+        CHECK(smax == 8, "ComputeSampleCountImage returns the maximum count (%d)", smax);
+        CHECK(img.SaveImage("/tmp/rtamd_render.png") && img.SaveZImage("/tmp/rtamd_z.png") && img.SaveSampleCountImage("/tmp/rtamd_samples.png"), "PNG outputs");
+        FILE* f = std::fopen("/tmp/rtamd_render.png", "rb");
+        unsigned char sig[8] = {0};
+        CHECK(f && std::fread(sig, 1, 8, f) == 8 && sig[1] == 'P' && sig[2] == 'N' && sig[3] == 'G', "PNG signature");
+        if (f) std::fclose(f);
+    }
 
     // progressive preview (RayCaster.cpp:1215-1279): 1-spp visits of bucket batches until every pixel holds maxSamples;
     // the same samples as the fixed 8-spp frame above, so the same image up to the order of the film's float atomics

@@ -159,3 +159,13 @@ class OraclePhotons:
         self.L.orc_photon_estimate(self.h, which, _vp(positions.ctypes.data), _vp(normals.ctypes.data),
                                    C.c_size_t(positions.shape[0]), _vp(out.ctypes.data))
         return out
+
+
+def median_denoise(linear, srgb=False):
+    """Oracle restatement of Denoiser::ApplyMedian (Denoiser.cpp:19-134)."""
+    src = np.ascontiguousarray(linear, dtype=np.float32)
+    H, W = src.shape[:2]
+    lin = np.empty_like(src)
+    rgb8 = np.empty((H, W, 3), dtype=np.uint8)
+    lib().orc_median_denoise(_vp(src.ctypes.data), W, H, int(bool(srgb)), _vp(lin.ctypes.data), _vp(rgb8.ctypes.data))
+    return lin, rgb8
