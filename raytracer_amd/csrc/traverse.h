@@ -278,11 +278,11 @@ __device__ __forceinline__ void trav_inner_step(TravState& s, const DevScene& sc
     else trav_pop(s, st);
 }
 
-// One leaf: up to 4 consecutive 48-byte records. Returns the number of triangles tested.
-__device__ __forceinline__ uint32_t trav_leaf_step(TravState& s, const DevScene& sc, TravStack& st, int hitSide) {
+// The records of one leaf reference (consecutive 48-byte records). Returns the number tested.
+__device__ __forceinline__ uint32_t trav_leaf_test(TravState& s, const DevScene& sc, uint32_t ref, int hitSide) {
     const float4* tris4 = reinterpret_cast<const float4*>(sc.tris);
-    const uint32_t first = (s.cur & 0x7FFFFFFFu) >> 3;
-    const uint32_t cnt = (s.cur & 7u) + 1u;
+    const uint32_t first = (ref & 0x7FFFFFFFu) >> 3;
+    const uint32_t cnt = (ref & 7u) + 1u;
     for (uint32_t k = 0; k < cnt; ++k) {
         const uint32_t slot = first + k;
         const float4 a = tris4[(size_t)slot * 3 + 0];
@@ -290,6 +290,11 @@ __device__ __forceinline__ uint32_t trav_leaf_step(TravState& s, const DevScene&
         const float4 c = tris4[(size_t)slot * 3 + 2];
         test_primitive(sc, a, b, c, s.r, hitSide, slot, s.best, s.bestPrim);
     }
+    return cnt;
+}
+// One leaf: test it, then continue with the next subtree on the stack.
+__device__ __forceinline__ uint32_t trav_leaf_step(TravState& s, const DevScene& sc, TravStack& st, int hitSide) {
+    const uint32_t cnt = trav_leaf_test(s, sc, s.cur, hitSide);
     trav_pop(s, st);
     return cnt;
 }
