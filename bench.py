@@ -129,6 +129,7 @@ def main():
         res = ra.film_resolve(film, cam)
         finite = bool(np.isfinite(res["linear"]).all())
         achieved = agg["ext_rays"] * bytes_per_ray / (agg["extend_ms"] * 1e-3) / 1e9 if agg["extend_ms"] > 0 else 0.0
+        traffic, traffic_src = measured_traffic(a, world)
         out = {
             "metric": "Mrays/s, cerealBar 1080p 128spp path traced (all ray segments: primary + bounce + shadow hops)",
             "value": rays_all / dt_max / 1e6,
@@ -150,7 +151,8 @@ def main():
             "image_finite": finite,
             "mean_linear": float(res["linear"].mean()),
             "roofline": {"bound": "hbm", "kernel": "extend_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": bytes_per_ray * agg["ext_rays"] / max(1, agg["launches"]),
                          "bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
                          "avg_launch_ms": agg["extend_ms"] / max(1, agg["launches"]), "launches": agg["launches"],
                          "extend_Mrays_s": agg["ext_rays"] / max(1e-9, agg["extend_ms"]) / 1e3},
@@ -163,6 +165,22 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(a, world):
+    """HBM-side bytes per extend launch from the PMC passes of this same workload (tools/pmc_traffic.sh, committed under
+    profiles/): 2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md "HBM") + WRITE_SIZE over the
+    launches. A PMC run cannot be nested inside this process, so the figure is the committed measurement; it is
+    reported only when this run is the configuration it was measured on."""
+    path = os.path.join(ROOT, "profiles", "r01", "extend_traffic_c3.json")
+    default = (a.tri_scale == 1.0 and a.width == 1920 and a.height == 1080 and a.spp == 128 and a.max_bounces == 64 and
+               world == 1)
+    if not default or not os.path.exists(path):
+        return None, None
+    k = json.load(open(path))["kernels"].get("extend_kernel<false>")
+    if not k or not k["dispatches"]:
+        return None, None
+    return (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 / k["dispatches"], "profiles/r01/extend_traffic_c3.json"
 
 
 def cpu_baseline(sd, cam, a):

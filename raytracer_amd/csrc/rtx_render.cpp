@@ -226,6 +226,11 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
         const size_t budget = std::min<size_t>((size_t)(0.4 * (double)freeB), (size_t)96 << 30);
         const size_t target = std::max<size_t>(budget / perSlot, 1u << 20);
         S = (int)std::max<size_t>(1, std::min<size_t>((size_t)perRound, target / std::max<uint32_t>(nPix, 1)));
+        // a pool kept from an earlier call is memory already paid for (and no longer "free"): use all of it
+        if (s->pool && nPix) {
+            const uint32_t have = reinterpret_cast<PathPoolHost*>(s->pool)->capacity / nPix;
+            S = std::max(S, (int)std::min<uint32_t>(have, (uint32_t)perRound));
+        }
     }
     S = std::min(S, perRound);
     // slot * 8 + light must fit 32 bits (shadow queue entries)

@@ -1,0 +1,30 @@
+#!/bin/bash
+# HBM-side traffic of the extend kernel for the bench workload: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
+# never combined with trace domains), summed over the extend launches of one frame.
+#   tools/pmc_traffic.sh [bench args]   ->  gpurun_out/extend_traffic.json
+args="--steps 1 --warmup 0 --no-cpu-baseline $*"
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+mkdir -p gpurun_out
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf gpurun_out/pmc_traffic_$c
+  timeout -s KILL 400 rocprofv3 --pmc $c -d gpurun_out/pmc_traffic_$c --output-format csv -- python3 bench.py $args > gpurun_out/pmc_traffic_$c.log 2>&1 || { echo "pass $c failed"; tail -5 gpurun_out/pmc_traffic_$c.log; exit 1; }
+done
+python3 - "$args" <<'PY'
+import csv, glob, json, sys
+out = {"command": "bench.py " + sys.argv[1], "kernels": {}}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(f"gpurun_out/pmc_traffic_{c}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f, newline="")):
+            if r["Counter_Name"] != c:
+                continue
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            d = out["kernels"].setdefault(k, {"FETCH_SIZE_KB": 0.0, "WRITE_SIZE_KB": 0.0, "dispatches": set()})
+            d[c + "_KB"] += float(r["Counter_Value"])
+            d["dispatches"].add(r["Dispatch_Id"])
+for k, d in out["kernels"].items():
+    d["dispatches"] = len(d["dispatches"])
+json.dump(out, open("gpurun_out/extend_traffic.json", "w"), indent=1)
+for k, d in sorted(out["kernels"].items(), key=lambda kv: -kv[1]["FETCH_SIZE_KB"])[:8]:
+    print(f'{k:40s} launches {d["dispatches"]:5d}  FETCH {d["FETCH_SIZE_KB"]/1e6:9.3f} GB  WRITE {d["WRITE_SIZE_KB"]/1e6:9.3f} GB')
+PY
+rm -rf gpurun_out/pmc_traffic_FETCH_SIZE gpurun_out/pmc_traffic_WRITE_SIZE
