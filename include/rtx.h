@@ -47,6 +47,11 @@ extern "C" {
 
 #define RTX_MTL_BLINN 0            /* Shading.cpp:715-725 */
 #define RTX_MTL_PHONG 1            /* Shading.cpp:727-737 */
+#define RTX_MTL_MICROFACET 2       /* MtlMicrofacet, Shading.cpp:741-936 (FBX import): diffuse = baseColor,
+                                      specular[0] = roughness, reflection[0] = metallic, refraction = transmittance
+                                      (the *_tex slots are their maps: a float map scales by the texel's red
+                                      channel), ior, absorption, bump as for the other types; emission is ignored
+                                      (RayCaster.cpp:158-161) and the albedo guide is 0.5 (:135-138) */
 
 #define RTX_TEX_RGB8 0             /* Color24 texels (PNG)            */
 #define RTX_TEX_RGB32F 1           /* float texels (Radiance HDR)     */

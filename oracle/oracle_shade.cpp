@@ -649,13 +649,182 @@ static void evaluate_phong_blinn(const PhongCtx& ctx, bool phong, const SInfo& s
     si.dist = 0.0f;
 }
 
+// ---- MtlMicrofacet (Shading.cpp:741-936) ----
+static inline float ggx_d(float alpha2, float NoH) {   // :741-745
+    float denom = NoH * NoH * (alpha2 - 1.0f) + 1.0f;
+    return alpha2 / (PI_F * denom * denom);
+}
+static inline float ggx_g1(float alpha2, float NoX) {   // :747-751
+    float denom = NoX + std::sqrt(alpha2 + (1.0f - alpha2) * NoX * NoX);
+    return (2.0f * NoX) / denom;
+}
+static inline V3 fresnel_schlick(V3 F0, float VoH) {   // :758-762
+    float k = std::pow(1.0f - VoH, 5.0f);
+    return F0 + (V3(1.0f) - F0) * k;
+}
+struct MicroCtx {
+    V3 N, V, F0, diffuse, trans;
+    float alpha, ior, pd, ps, pt, total;
+};
+// common prologue of GenerateSample / GetSampleInfo (:768-785, :861-879); float maps scale by the texel's red channel
+static MicroCtx build_micro(const Scene& sc, const rtx_material_desc& m, const SInfo& s) {
+    MicroCtx c;
+    c.N = normalized(s.N);
+    if (!s.front) c.N = -c.N;
+    c.V = safe_normalize(s.V);
+    const V3 base = sc.eval_tc(m.diffuse, m.diffuse_tex, s.uvw);
+    float rough = m.specular[0], metal = m.reflection[0];
+    if (m.specular_tex >= 0) rough *= sc.texmaps[m.specular_tex].eval(s.uvw).x;
+    if (m.reflection_tex >= 0) metal *= sc.texmaps[m.reflection_tex].eval(s.uvw).x;
+    rough = clamp01(rough);
+    metal = clamp01(metal);
+    c.trans = sc.eval_tc(m.refraction, m.refraction_tex, s.uvw);
+    c.alpha = std::max(0.002f, rough * rough);
+    c.F0 = V3(0.04f) * (1.0f - metal) + base * metal;
+    c.diffuse = base * (1.0f - metal);
+    c.ior = m.ior;
+    c.pd = luma1(c.diffuse);
+    c.ps = luma1(c.F0);
+    c.pt = luma1(c.trans);
+    c.total = c.pd + c.ps + c.pt;
+    return c;
+}
+static bool sample_microfacet(const MicroCtx& c, const SInfo& sInfo, V3& dir, DirInfo& si) {   // :765-856
+    si.set_void();
+    const V3 N = c.N, V = c.V;
+    if (c.total <= 0.0f) return false;
+    const float r = sInfo.rnd(DIM_LOBE) * c.total;
+    const float u1 = sInfo.rnd(DIM_U1), u2 = sInfo.rnd(DIM_U2);
+    if (r < c.pd) {
+        V3 U, Vb;
+        build_onb(N, U, Vb);
+        float rxy = std::sqrt(u1);
+        float phi = 2.0f * PI_F * u2;
+        float x = rxy * std::cos(phi);
+        float y = rxy * std::sin(phi);
+        float z = std::sqrt(std::max(0.0f, 1.0f - u1));
+        dir = safe_normalize(U * x + Vb * y + N * z);
+        float cosN = std::max(0.0f, dot(N, dir));
+        float pdf = cosN / PI_F;
+        si.mult = c.diffuse * (1.0f / PI_F) * cosN;
+        si.prob = (c.pd / c.total) * pdf;
+        si.dist = 0.0f;
+        si.lobe = LOBE_DIFFUSE;
+        return si.prob > 0.0f && vmax(si.mult) > 0.0f;
+    } else if (r < c.pd + c.ps) {
+        V3 U, Vb;
+        build_onb(N, U, Vb);
+        float phi = 2.0f * PI_F * u1;
+        float cosT = std::sqrt((1.0f - u2) / (1.0f + (c.alpha * c.alpha - 1.0f) * u2));
+        float sinT = std::sqrt(std::max(0.0f, 1.0f - cosT * cosT));
+        V3 h = safe_normalize(U * (std::cos(phi) * sinT) + Vb * (std::sin(phi) * sinT) + N * cosT);
+        dir = reflect(-V, h);
+        if (dot(N, dir) <= 0.0f) return false;
+        float NoV = std::max(0.0f, dot(N, V));
+        float NoL = std::max(0.0f, dot(N, dir));
+        float NoH = std::max(0.0f, dot(N, h));
+        float VoH = std::max(0.0f, dot(V, h));
+        float alpha2 = c.alpha * c.alpha;
+        float D = ggx_d(alpha2, NoH);
+        float G = ggx_g1(alpha2, NoL) * ggx_g1(alpha2, NoV);
+        V3 F = fresnel_schlick(c.F0, VoH);
+        si.mult = (F * (D * G)) / std::max(1e-6f, 4.0f * NoV);
+        float pdfDir = (D * NoH) / std::max(1e-6f, 4.0f * VoH);
+        si.prob = (c.ps / c.total) * pdfDir;
+        si.dist = 0.0f;
+        si.lobe = LOBE_SPECULAR;
+        return si.prob > 0.0f && vmax(si.mult) > 0.0f;
+    } else {
+        float eta = sInfo.front ? 1.0f / c.ior : c.ior;
+        V3 I = -V;
+        float cosI = clamp01(-dot(N, I));
+        float k = 1.0f - eta * eta * (1.0f - cosI * cosI);
+        if (k < 0.0f) return false;
+        V3 T = eta * I + (eta * cosI - std::sqrt(k)) * N;
+        dir = safe_normalize(T);
+        float etaScale = transmission_scale(eta);
+        si.mult = c.trans * etaScale;
+        si.prob = c.pt / c.total;
+        si.dist = -1.0f;
+        si.lobe = LOBE_TRANSMISSION;
+        return si.prob > 0.0f && vmax(si.mult) > 0.0f;
+    }
+}
+static void evaluate_microfacet(const MicroCtx& c, const SInfo& sInfo, V3 dirIn, DirInfo& si) {   // :858-934
+    si.set_void();
+    const V3 N = c.N, V = c.V;
+    const V3 L = safe_normalize(dirIn);
+    if (c.total <= 0.0f) return;
+    float NoL = dot(N, L);
+    V3 mult(0.0f);
+    float pdf = 0.0f;
+    int lobe = LOBE_NONE;
+    if (NoL > 0.0f) {
+        V3 fDiff = c.diffuse * (1.0f / PI_F) * NoL;
+        float pdfDiff = (c.pd > 0.0f) ? (NoL / PI_F) * (c.pd / c.total) : 0.0f;
+        V3 H = safe_normalize(L + V);
+        float NoV = std::max(0.0f, dot(N, V));
+        float NoH = std::max(0.0f, dot(N, H));
+        float VoH = std::max(0.0f, dot(V, H));
+        float pdfSpec = 0.0f;
+        V3 fSpec(0.0f);
+        if (c.ps > 0.0f && VoH > 0.0f) {
+            float alpha2 = c.alpha * c.alpha;
+            float D = ggx_d(alpha2, NoH);
+            float G = ggx_g1(alpha2, NoL) * ggx_g1(alpha2, NoV);
+            V3 F = fresnel_schlick(c.F0, VoH);
+            fSpec = (F * (D * G)) / std::max(1e-6f, 4.0f * NoV);
+            pdfSpec = (D * NoH) / std::max(1e-6f, 4.0f * VoH);
+            pdfSpec *= (c.ps / c.total);
+        }
+        mult = fDiff + fSpec;
+        pdf = pdfDiff + pdfSpec;
+        lobe = (c.ps > 0.0f && c.pd > 0.0f) ? LOBE_ALL : (c.ps > 0.0f ? LOBE_SPECULAR : LOBE_DIFFUSE);
+    } else if (c.pt > 0.0f) {
+        float eta = sInfo.front ? 1.0f / c.ior : c.ior;
+        V3 I = -V;
+        float cosI = -dot(N, I);
+        float k = 1.0f - eta * eta * (1.0f - cosI * cosI);
+        if (k < 0.0f) return;
+        float cosT = std::sqrt(k);
+        V3 T = safe_normalize(eta * I + (eta * cosI - cosT) * N);
+        if (dot(T, L) < 1.0f - 1e-4f) return;
+        mult = c.trans * transmission_scale(eta);
+        pdf = c.pt / c.total;
+        lobe = LOBE_TRANSMISSION;
+    }
+    if (pdf <= 0.0f || vmax(mult) <= 0.0f) return;
+    si.mult = mult;
+    si.prob = pdf;
+    si.dist = 0.0f;
+    si.lobe = lobe;
+}
+
 bool mtl_generate_sample(const Scene& sc, const Material& m, const SInfo& s, V3& dir, DirInfo& si) {
+    if (m.d.type == RTX_MTL_MICROFACET) return sample_microfacet(build_micro(sc, m.d, s), s, dir, si);
     PhongCtx ctx = build_ctx(sc, m.d, s);  // Shading.cpp:715-719 / 727-731
     return sample_phong_blinn(ctx, m.d.type == RTX_MTL_PHONG, s, dir, si);
 }
 void mtl_get_sample_info(const Scene& sc, const Material& m, const SInfo& s, V3 dir, DirInfo& si) {
+    if (m.d.type == RTX_MTL_MICROFACET) {
+        evaluate_microfacet(build_micro(sc, m.d, s), s, dir, si);
+        return;
+    }
     PhongCtx ctx = build_ctx(sc, m.d, s);  // Shading.cpp:721-725 / 733-737
     evaluate_phong_blinn(ctx, m.d.type == RTX_MTL_PHONG, s, dir, si);
+}
+// GetDiffuseAlbedo / GetEmission / IsPhotonSurface as the path loop sees them (RayCaster.cpp:135-138, :158-161)
+V3 mtl_diffuse_albedo(const Scene& sc, const Material& m, const SInfo& s) {
+    if (m.d.type == RTX_MTL_MICROFACET) return V3(0.5f);
+    return sc.eval_tc(m.d.diffuse, m.d.diffuse_tex, s.uvw);
+}
+V3 mtl_emission(const Scene& sc, const Material& m, const SInfo& s) {
+    if (m.d.type == RTX_MTL_MICROFACET) return V3(0.0f);
+    return sc.eval_tc(m.d.emission, m.d.emission_tex, s.uvw);
+}
+bool mtl_is_photon_surface(const Material& m) {
+    const float k = m.d.type == RTX_MTL_MICROFACET ? 1.0f - clamp01(m.d.reflection[0]) : 1.0f;
+    return (m.d.diffuse[0] + m.d.diffuse[1] + m.d.diffuse[2]) * k > 0.0f;
 }
 
 // BumpMapping.h:9-70
@@ -866,7 +1035,7 @@ PathResult trace_path(const Scene& scene, const Camera& camera, Ray ray, int px,
         if (firstHit) {
             primaryDist = hitDist;
             firstHit = false;
-            firstAlbedo = mtl ? scene.eval_tc(mtl->d.diffuse, mtl->d.diffuse_tex, sInfo.uvw) : V3(0.5f);  // :135-138
+            firstAlbedo = mtl ? mtl_diffuse_albedo(scene, *mtl, sInfo) : V3(0.5f);  // :135-138
             firstNormal = safe_normalize(h.GN);
             haveFirstHit = true;
         }
@@ -893,7 +1062,7 @@ PathResult trace_path(const Scene& scene, const Camera& camera, Ray ray, int px,
         }
         if (!mtl) break;
 
-        V3 emission = scene.eval_tc(mtl->d.emission, mtl->d.emission_tex, sInfo.uvw);
+        V3 emission = mtl_emission(scene, *mtl, sInfo);
         if (vmax(emission) > 0.0f) L = L + beta * emission;
 
         V3 direct(0, 0, 0);
@@ -936,12 +1105,12 @@ PathResult trace_path(const Scene& scene, const Camera& camera, Ray ray, int px,
 
         if (mapper) {
             const PhotonMap& cm = mapper->caustic;
-            bool photonSurface = (mtl->d.diffuse[0] + mtl->d.diffuse[1] + mtl->d.diffuse[2]) > 0.0f;  // IsPhotonSurface
+            bool photonSurface = mtl_is_photon_surface(*mtl);  // IsPhotonSurface
             if (!cm.ph.empty() && photonSurface) {
                 int maxPhotons = mapper->searchCount <= 30 ? 30 : (mapper->searchCount <= 50 ? 50 : 100);
                 V3 irrad = cm.estimate(maxPhotons, mapper->causticRadius, h.p, h.N);
                 if (vmax(irrad) > 0.0f) {
-                    V3 kd = scene.eval_tc(mtl->d.diffuse, mtl->d.diffuse_tex, sInfo.uvw);
+                    V3 kd = mtl_diffuse_albedo(scene, *mtl, sInfo);
                     irrad = irrad * kCausticBoost;
                     float causticScale = 0.1f + 0.9f * maxVisibility;
                     L = L + beta * (kd * (1.0f / PI_F) * irrad * causticScale);
@@ -1258,7 +1427,7 @@ static void trace_photon(const Scene& scene, PhotonMapper& pm, uint64_t seed, ui
         V3 hitPos = hInfo.p;
         V3 N = normalized(hInfo.N);
         bool inside = dot(ray.dir, N) > 0.0f;
-        bool isDiffuseSurface = (mtl->d.diffuse[0] + mtl->d.diffuse[1] + mtl->d.diffuse[2]) > 0.0f;
+        bool isDiffuseSurface = mtl_is_photon_surface(*mtl);
         bool storeAsCaustic = causticPath && hasTransmitted && !hasHitDiffuse && isDiffuseSurface;
         if (bounce >= 1 && isDiffuseSurface) {
             V3 d = normalized(ray.dir);

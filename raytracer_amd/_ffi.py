@@ -12,7 +12,7 @@ c_int_p = C.POINTER(C.c_int)
 
 HIT_FRONT, HIT_BACK, HIT_FRONT_AND_BACK = 1, 2, 3
 BIGFLOAT = 1.0e30
-MTL_BLINN, MTL_PHONG = 0, 1
+MTL_BLINN, MTL_PHONG, MTL_MICROFACET = 0, 1, 2
 OBJ_MESH, OBJ_SPHERE, OBJ_PLANE = 0, 1, 2
 TEX_RGB8, TEX_RGB32F = 0, 1
 FILTER_TENT, FILTER_GAUSSIAN, FILTER_MITCHELL, FILTER_LANCZOS = 0, 1, 2, 3

@@ -370,6 +370,162 @@ __device__ __forceinline__ void evaluate_phong_blinn(const PhongCtx& ctx, bool p
     si.lobe = lobe;
 }
 
+// ---- MtlMicrofacet (Shading.cpp:741-936; materials of FBX imports) -------------------------------------------
+struct MicroCtx {
+    f3 N, V, F0, diffuse, trans;
+    float alpha, ior, pd, ps, pt, total;
+};
+__device__ __forceinline__ float ggx_d(float alpha2, float NoH) {   // :741-745
+    const float denom = NoH * NoH * (alpha2 - 1.0f) + 1.0f;
+    return alpha2 / (PI_F * denom * denom);
+}
+__device__ __forceinline__ float ggx_g1(float alpha2, float NoX) {   // :747-751
+    const float denom = NoX + sqrtf(alpha2 + (1.0f - alpha2) * NoX * NoX);
+    return (2.0f * NoX) / denom;
+}
+__device__ __forceinline__ f3 fresnel_schlick(f3 F0, float VoH) {   // :758-762
+    const float k = powf(1.0f - VoH, 5.0f);
+    return F0 + (mk3(1.0f) - F0) * k;
+}
+// common prologue of GenerateSample / GetSampleInfo (:768-785, :861-879), built once per hit; material slots as
+// described at RTX_MTL_MICROFACET in rtx.h
+__device__ __forceinline__ MicroCtx build_micro_ctx(const DevScene& sc, const DevMaterial& m, const SampCtx& s) {
+    MicroCtx c;
+    c.N = normalized3(s.N);
+    if (!s.front) c.N = -c.N;
+    c.V = safe_normalize3(s.V);
+    const f3 base = eval_tc(sc, m.kd, m.kd_tex, s.uvw);
+    float rough = m.ks[0], metal = m.kr[0];
+    if (m.ks_tex >= 0) rough *= tex_eval(sc, m.ks_tex, s.uvw).x;
+    if (m.kr_tex >= 0) metal *= tex_eval(sc, m.kr_tex, s.uvw).x;
+    rough = clamp01f(rough);
+    metal = clamp01f(metal);
+    c.trans = eval_tc(sc, m.kt, m.kt_tex, s.uvw);
+    c.alpha = fmaxf(0.002f, rough * rough);
+    c.F0 = mk3(0.04f) * (1.0f - metal) + base * metal;
+    c.diffuse = base * (1.0f - metal);
+    c.ior = m.ior;
+    c.pd = luma1(c.diffuse);
+    c.ps = luma1(c.F0);
+    c.pt = luma1(c.trans);
+    c.total = c.pd + c.ps + c.pt;
+    return c;
+}
+__device__ __forceinline__ bool sample_microfacet(const MicroCtx& c, const SampCtx& s, f3& dir, DirInfo& si) {   // :765-856
+    set_void(si);
+    if (c.total <= 0.0f) return false;
+    const f3 N = c.N, V = c.V;
+    const float r = s.rnd(DIM_LOBE) * c.total;
+    const float u1 = s.rnd(DIM_U1), u2 = s.rnd(DIM_U2);
+    if (r < c.pd) {
+        f3 U, Vb;
+        build_onb(N, U, Vb);
+        const float rxy = sqrtf(u1);
+        const float phi = 2.0f * PI_F * u2;
+        const float x = rxy * cosf(phi);
+        const float y = rxy * sinf(phi);
+        const float z = sqrtf(fmaxf(0.0f, 1.0f - u1));
+        dir = safe_normalize3(U * x + Vb * y + N * z);
+        const float cosN = fmaxf(0.0f, dot3(N, dir));
+        const float pdf = cosN / PI_F;
+        si.mult = c.diffuse * (1.0f / PI_F) * cosN;
+        si.prob = (c.pd / c.total) * pdf;
+        si.dist = 0.0f;
+        si.lobe = LOBE_DIFFUSE;
+        return si.prob > 0.0f && max3c(si.mult) > 0.0f;
+    } else if (r < c.pd + c.ps) {
+        f3 U, Vb;
+        build_onb(N, U, Vb);
+        const float phi = 2.0f * PI_F * u1;
+        const float cosT = sqrtf((1.0f - u2) / (1.0f + (c.alpha * c.alpha - 1.0f) * u2));
+        const float sinT = sqrtf(fmaxf(0.0f, 1.0f - cosT * cosT));
+        const f3 h = safe_normalize3(U * (cosf(phi) * sinT) + Vb * (sinf(phi) * sinT) + N * cosT);
+        dir = reflect3(-V, h);
+        if (dot3(N, dir) <= 0.0f) return false;
+        const float NoV = fmaxf(0.0f, dot3(N, V));
+        const float NoL = fmaxf(0.0f, dot3(N, dir));
+        const float NoH = fmaxf(0.0f, dot3(N, h));
+        const float VoH = fmaxf(0.0f, dot3(V, h));
+        const float alpha2 = c.alpha * c.alpha;
+        const float D = ggx_d(alpha2, NoH);
+        const float G = ggx_g1(alpha2, NoL) * ggx_g1(alpha2, NoV);
+        const f3 F = fresnel_schlick(c.F0, VoH);
+        si.mult = (F * (D * G)) / fmaxf(1e-6f, 4.0f * NoV);
+        const float pdfDir = (D * NoH) / fmaxf(1e-6f, 4.0f * VoH);
+        si.prob = (c.ps / c.total) * pdfDir;
+        si.dist = 0.0f;
+        si.lobe = LOBE_SPECULAR;
+        return si.prob > 0.0f && max3c(si.mult) > 0.0f;
+    } else {
+        const float eta = s.front ? 1.0f / c.ior : c.ior;
+        const f3 I = -V;
+        const float cosI = clamp01f(-dot3(N, I));
+        const float k = 1.0f - eta * eta * (1.0f - cosI * cosI);
+        if (k < 0.0f) return false;
+        const f3 T = eta * I + (eta * cosI - sqrtf(k)) * N;
+        dir = safe_normalize3(T);
+        si.mult = c.trans * transmission_scale(eta);
+        si.prob = c.pt / c.total;
+        si.dist = -1.0f;   // delta transmission
+        si.lobe = LOBE_TRANSMISSION;
+        return si.prob > 0.0f && max3c(si.mult) > 0.0f;
+    }
+}
+__device__ __forceinline__ void evaluate_microfacet(const MicroCtx& c, const SampCtx& s, f3 dirIn, DirInfo& si) {   // :858-934
+    set_void(si);
+    if (c.total <= 0.0f) return;
+    const f3 N = c.N, V = c.V;
+    const f3 L = safe_normalize3(dirIn);
+    const float NoL = dot3(N, L);
+    f3 mult = mk3(0.0f);
+    float pdf = 0.0f;
+    int lobe = LOBE_NONE;
+    if (NoL > 0.0f) {
+        const f3 fDiff = c.diffuse * (1.0f / PI_F) * NoL;
+        const float pdfDiff = (c.pd > 0.0f) ? (NoL / PI_F) * (c.pd / c.total) : 0.0f;
+        const f3 H = safe_normalize3(L + V);
+        const float NoV = fmaxf(0.0f, dot3(N, V));
+        const float NoH = fmaxf(0.0f, dot3(N, H));
+        const float VoH = fmaxf(0.0f, dot3(V, H));
+        float pdfSpec = 0.0f;
+        f3 fSpec = mk3(0.0f);
+        if (c.ps > 0.0f && VoH > 0.0f) {
+            const float alpha2 = c.alpha * c.alpha;
+            const float D = ggx_d(alpha2, NoH);
+            const float G = ggx_g1(alpha2, NoL) * ggx_g1(alpha2, NoV);
+            const f3 F = fresnel_schlick(c.F0, VoH);
+            fSpec = (F * (D * G)) / fmaxf(1e-6f, 4.0f * NoV);
+            pdfSpec = (D * NoH) / fmaxf(1e-6f, 4.0f * VoH);
+            pdfSpec *= (c.ps / c.total);
+        }
+        mult = fDiff + fSpec;
+        pdf = pdfDiff + pdfSpec;
+        lobe = (c.ps > 0.0f && c.pd > 0.0f) ? LOBE_ALL : (c.ps > 0.0f ? LOBE_SPECULAR : LOBE_DIFFUSE);
+    } else if (c.pt > 0.0f) {
+        const float eta = s.front ? 1.0f / c.ior : c.ior;
+        const f3 I = -V;
+        const float cosI = -dot3(N, I);
+        const float k = 1.0f - eta * eta * (1.0f - cosI * cosI);
+        if (k < 0.0f) return;
+        const float cosT = sqrtf(k);
+        const f3 T = safe_normalize3(eta * I + (eta * cosI - cosT) * N);
+        if (dot3(T, L) < 1.0f - 1e-4f) return;   // only the delta refraction direction counts
+        mult = c.trans * transmission_scale(eta);
+        pdf = c.pt / c.total;
+        lobe = LOBE_TRANSMISSION;
+    }
+    if (pdf <= 0.0f || max3c(mult) <= 0.0f) return;
+    si.mult = mult;
+    si.prob = pdf;
+    si.dist = 0.0f;
+    si.lobe = lobe;
+}
+// IsPhotonSurface stand-in: some diffuse reflectance
+__device__ __forceinline__ bool mtl_is_photon_surface(const DevMaterial& m) {
+    const float k = m.type == RTX_MTL_MICROFACET ? 1.0f - clamp01f(m.kr[0]) : 1.0f;
+    return (m.kd[0] + m.kd[1] + m.kd[2]) * k > 0.0f;
+}
+
 // ---- PointLight -------------------------------------------------------------------------------------------
 // Shading.cpp:118-165
 __device__ __forceinline__ bool light_generate_sample(const DevLight& L, f3 P, float u1, float u2, f3& dir, DirInfo& si) {

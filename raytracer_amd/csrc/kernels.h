@@ -57,7 +57,8 @@ uint32_t launch_raygen(const DevCamera& cam, const PathPool& pool, const int* pi
                        const SegQ& qOut, uint32_t* queueOut, hipStream_t stream);
 uint32_t launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm, const SegQ& qIn,
                       const uint32_t* queueIn, uint32_t n, int bounce, int maxBounces, unsigned long long seed, int sBase, int S,
-                      const int* pixels, const SegQ& qOut, uint32_t* queueOut, const SegQ& qShadow, hipStream_t stream);
+                      const int* pixels, const SegQ& qOut, uint32_t* queueOut, const SegQ& qShadow, int hasMicrofacet,
+                      hipStream_t stream);
 void launch_shadow(const DevScene& sc, const LaunchCfg& cfg, const PathPool& pool, const SegQ& q, uint32_t n, int useTransmittance);
 void launch_resolve(const PathPool& pool, const SegQ& qIn, const uint32_t* queueIn, uint32_t n, int nLights, int usePhotons,
                     hipStream_t stream);

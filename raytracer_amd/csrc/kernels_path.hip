@@ -151,6 +151,8 @@ __device__ __forceinline__ bool has_map_or_value(const float* c, int tex) {   //
 #ifndef SHADE_WAVES_PER_EU
 #define SHADE_WAVES_PER_EU 3
 #endif
+// MICRO: the scene holds MtlMicrofacet materials (a second BSDF in the kernel; scenes without them run the leaner one)
+template <bool MICRO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES_PER_EU))) void shade_kernel(DevScene sc, DevCamera cam, PathPool pool, DevPhotonMap pm,
                                                     SegQ qIn, const uint32_t* __restrict__ queueIn, uint32_t n, int bounce,
                                                     int maxBounces, unsigned long long seed, int sBase, int S,
@@ -227,9 +229,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
             sx.key = rng_key(seed, (uint32_t)pix, (uint32_t)sIdx);
             sx.stream = (uint32_t)bounce;
 
-            if (bounce == 0) {   // :401-407
+            const bool micro = MICRO && mtl && mtl->type == RTX_MTL_MICROFACET;
+            if (bounce == 0) {   // :401-407, GetDiffuseAlbedo :135-138
                 L4.w = hitDist;
-                const f3 alb = mtl ? eval_tc(sc, mtl->kd, mtl->kd_tex, sx.uvw) : mk3(0.5f);
+                const f3 alb = (mtl && !micro) ? eval_tc(sc, mtl->kd, mtl->kd_tex, sx.uvw) : mk3(0.5f);
                 const f3 fn = safe_normalize3(sh.GN);
                 pool.albedo[slot] = make_float4(alb.x, alb.y, alb.z, 1.0f);
                 pool.normal[slot] = make_float4(fn.x, fn.y, fn.z, 1.0f);
@@ -258,14 +261,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
             }
             if (!mtl) break;
 
-            const f3 emission = eval_tc(sc, mtl->ke, mtl->ke_tex, sx.uvw);   // :445-446
+            const f3 emission = micro ? mk3(0.0f) : eval_tc(sc, mtl->ke, mtl->ke_tex, sx.uvw);   // :445-446, GetEmission :158-161
             if (max3c(emission) > 0.0f) L = L + beta * emission;
 
-            const PhongCtx ctx = build_phong_ctx(sc, *mtl, sx);
+            PhongCtx ctx;
+            MicroCtx mctx;
+            if (micro) mctx = build_micro_ctx(sc, *mtl, sx);
+            else ctx = build_phong_ctx(sc, *mtl, sx);
             const bool phong = mtl->type == RTX_MTL_PHONG;
 
             // ---- next event estimation: contributions now, visibility by the shadow kernel (:456-503) ----
-            const bool photonSurface = (mtl->kd[0] + mtl->kd[1] + mtl->kd[2]) > 0.0f;
+            const bool photonSurface = mtl_is_photon_surface(*mtl);
             const bool wantCaustic = pm.n > 0 && photonSurface;
             for (int l = 0; l < sc.n_lights; ++l) {
                 const DevLight& light = sc.lights[l];
@@ -276,7 +282,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
                 if (light_generate_sample(light, sx.P, u1, u2, ldir, li) && li.prob > 0.0f && max3c(li.mult) > 0.0f) {
                     const float shadowMax = (li.dist > 0.0f && li.dist < RTX_BIG * 0.5f) ? li.dist : RTX_BIG;
                     DirInfo bs;
-                    evaluate_phong_blinn(ctx, phong, sx, safe_normalize3(ldir), bs);
+                    if (micro) evaluate_microfacet(mctx, sx, safe_normalize3(ldir), bs);
+                    else evaluate_phong_blinn(ctx, phong, sx, safe_normalize3(ldir), bs);
                     f3 c = mk3(0.0f);
                     if (bs.prob > 0.0f && max3c(bs.mult) > 0.0f) {
                         if (light.size > 0.0f) {
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
                 if (photonSurface) {
                     f3 irrad = estimate_irradiance(pm, sh.p, sh.N);
                     if (max3c(irrad) > 0.0f) {
-                        const f3 kd = eval_tc(sc, mtl->kd, mtl->kd_tex, sx.uvw);
+                        const f3 kd = micro ? mk3(0.5f) : eval_tc(sc, mtl->kd, mtl->kd_tex, sx.uvw);
                         irrad = irrad * 0.1f;   // kCausticBoost
                         const f3 t = kd * (1.0f / PI_F) * irrad;
                         cz = make_float4(t.x, t.y, t.z, 1.0f);
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
             // ---- BSDF sampling for the next bounce (:525-566) ----
             f3 nextDir;
             DirInfo bsd;
-            if (!sample_phong_blinn(ctx, phong, sx, nextDir, bsd)) break;
+            if (micro ? !sample_microfacet(mctx, sx, nextDir, bsd) : !sample_phong_blinn(ctx, phong, sx, nextDir, bsd)) break;
             if (bsd.prob <= 0.0f || max3c(bsd.mult) <= 0.0f) break;
             const float pdfThroughput = fmaxf(1e-4f, bsd.prob);
             beta = beta * (bsd.mult / pdfThroughput);
@@ -747,11 +754,16 @@ uint32_t launch_raygen(const DevCamera& cam, const PathPool& pool, const int* pi
 }
 uint32_t launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm, const SegQ& qIn,
                       const uint32_t* queueIn, uint32_t n, int bounce, int maxBounces, unsigned long long seed, int sBase, int S,
-                      const int* pixels, const SegQ& qOut, uint32_t* queueOut, const SegQ& qShadow, hipStream_t stream) {
+                      const int* pixels, const SegQ& qOut, uint32_t* queueOut, const SegQ& qShadow, int hasMicrofacet,
+                      hipStream_t stream) {
     if (!n) return 0;
     const uint32_t grid = (n + 255) / 256;
-    hipLaunchKernelGGL(shade_kernel, dim3(grid), dim3(256), 0, stream, sc, cam, pool, pm, qIn, queueIn, n, bounce, maxBounces, seed, sBase,
-                       S, pixels, qOut, queueOut, qShadow);
+    if (hasMicrofacet)
+        hipLaunchKernelGGL(shade_kernel<true>, dim3(grid), dim3(256), 0, stream, sc, cam, pool, pm, qIn, queueIn, n, bounce, maxBounces,
+                           seed, sBase, S, pixels, qOut, queueOut, qShadow);
+    else
+        hipLaunchKernelGGL(shade_kernel<false>, dim3(grid), dim3(256), 0, stream, sc, cam, pool, pm, qIn, queueIn, n, bounce, maxBounces,
+                           seed, sBase, S, pixels, qOut, queueOut, qShadow);
     return grid;
 }
 void launch_shadow(const DevScene& sc, const LaunchCfg& cfg, const PathPool& pool, const SegQ& q, uint32_t n, int useTransmittance) {

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void photon_emit_kernel(DevScene sc, in
             const f3 hitPos = sh.p;
             const f3 N = normalized3(sh.N);
             const bool inside = dot3(rd, N) > 0.0f;
-            const bool isDiffuseSurface = (mtl.kd[0] + mtl.kd[1] + mtl.kd[2]) > 0.0f;   // IsPhotonSurface
+            const bool isDiffuseSurface = mtl_is_photon_surface(mtl);   // IsPhotonSurface
             const bool storeAsCaustic = causticPath && hasTransmitted && !hasHitDiffuse && isDiffuseSurface;
             if (bounce >= 1 && isDiffuseSurface) {
                 const f3 d = normalized3(rd);
@@ -92,10 +92,15 @@ __global__ __launch_bounds__(TRAV_BLOCK) void photon_emit_kernel(DevScene sc, in
             sx.front = !inside;
             sx.key = key;
             sx.stream = (uint32_t)(bounce + 1);
-            const PhongCtx ctx = build_phong_ctx(sc, mtl, sx);
             f3 nextDir;
             DirInfo si;
-            if (!sample_phong_blinn(ctx, mtl.type == RTX_MTL_PHONG, sx, nextDir, si)) break;
+            if (mtl.type == RTX_MTL_MICROFACET) {
+                const MicroCtx mctx = build_micro_ctx(sc, mtl, sx);
+                if (!sample_microfacet(mctx, sx, nextDir, si)) break;
+            } else {
+                const PhongCtx ctx = build_phong_ctx(sc, mtl, sx);
+                if (!sample_phong_blinn(ctx, mtl.type == RTX_MTL_PHONG, sx, nextDir, si)) break;
+            }
             if (!hasHitDiffuse && si.lobe == LOBE_SPECULAR && max3c(si.mult) > 0.0f) break;   // :225-227
             const float continueProbability = fminf(0.5f, max3c(si.mult));                   // :231-237
             if (continueProbability < 1e-6f) break;

@@ -188,12 +188,13 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     for (int i = 0; i < desc->n_materials; ++i) {
         const rtx_material_desc& m = desc->materials[i];
         if (!texOK(m.diffuse_tex) || !texOK(m.specular_tex) || !texOK(m.reflection_tex) || !texOK(m.refraction_tex) ||
-            !texOK(m.emission_tex) || !texOK(m.bump_tex) || (m.type != RTX_MTL_BLINN && m.type != RTX_MTL_PHONG)) {
+            !texOK(m.emission_tex) || !texOK(m.bump_tex) || (m.type != RTX_MTL_BLINN && m.type != RTX_MTL_PHONG && m.type != RTX_MTL_MICROFACET)) {
             rtx_scene_destroy(s);
             return rtx_fail(RTX_ERR_INVALID, "material " + std::to_string(i) + ": bad texture index or type");
         }
         DevMaterial& o = mtls[i];
         o.type = m.type;
+        if (m.type == RTX_MTL_MICROFACET) s->hasMicrofacet = 1;
         std::memcpy(o.kd, m.diffuse, 12);    o.kd_tex = m.diffuse_tex;
         std::memcpy(o.ks, m.specular, 12);   o.ks_tex = m.specular_tex;
         std::memcpy(o.kr, m.reflection, 12); o.kr_tex = m.reflection_tex;

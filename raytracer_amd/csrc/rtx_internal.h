@@ -32,6 +32,7 @@ struct rtx_scene {
     int depth = 0;
     LaunchCfg cfg{};
     int numCUs = 0;
+    int hasMicrofacet = 0;        // some material is RTX_MTL_MICROFACET: selects the two-BSDF shade kernel
     std::atomic<int> cancel{0};   // rtx_cancel
     // reusable scratch for the host-array entry points
     DevBuf rays, hits, full, aux, aux2;

@@ -295,7 +295,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 out.extend_launches++;
                 tm.begin(2, st);
                 const uint32_t gridShade = launch_shade(s->dev, dc, pool, pm, sqIn, qin, n, bounce, rp->max_bounces, rp->seed, sBase, Sp,
-                                                        curPixels, sqOut, qout, pool.qS, st);
+                                                        curPixels, sqOut, qout, pool.qS, s->hasMicrofacet, st);
                 tm.end(st);
                 launch_segq_scan2(sqOut, gridShade, 1, pool.qS, gridShade, shadowMult, 256, pool.totals, st);
                 uint32_t cnt[2] = {0, 0};
