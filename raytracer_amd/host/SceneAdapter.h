@@ -21,6 +21,21 @@ inline void CollectSceneNodeObjects(const Scene& scene, vector<pair<const Node*,
     collect(&scene.rootNode, collect);
 }
 
+// The same DFS with the accumulated node -> root transform of every (Node, Object) pair.
+struct SceneNodeItem {
+    const Node* node;
+    Matrix34 world;
+};
+inline void CollectSceneNodeItems(const Scene& scene, std::vector<SceneNodeItem>& items, const Node* root = nullptr) {
+    auto walk = [&](const Node* n, const Matrix34& parent, auto& self) -> void {
+        if (!n) return;
+        Matrix34 w = Matrix34::Compose(parent, n->tm);
+        if (n->GetNodeObj()) items.push_back({n, w});
+        for (int i = 0; i < n->GetNumChild(); ++i) self(n->GetChild(i), w, self);
+    };
+    walk(root ? root : &scene.rootNode, Matrix34(), walk);
+}
+
 // Device-resident copy of a Scene (or of a sub-tree rooted at `root`). Owns the rtx_scene handle.
 class GpuScene {
 public:
@@ -58,18 +73,8 @@ private:
 
     void Build(const Scene& scene, const Node* root) {
         // DFS with accumulated transforms; the (Node,Object) order is CollectSceneNodeObjects' order
-        struct Item {
-            const Node* node;
-            Matrix34 world;
-        };
-        std::vector<Item> items;
-        auto walk = [&](const Node* n, const Matrix34& parent, auto& self) -> void {
-            if (!n) return;
-            Matrix34 w = Matrix34::Compose(parent, n->tm);
-            if (n->GetNodeObj()) items.push_back({n, w});
-            for (int i = 0; i < n->GetNumChild(); ++i) self(n->GetChild(i), w, self);
-        };
-        walk(root, Matrix34(), walk);
+        std::vector<SceneNodeItem> items;
+        CollectSceneNodeItems(scene, items, root);
 
         TexPool tex;
         std::map<const Material*, int> mtlIndex;

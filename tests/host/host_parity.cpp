@@ -10,6 +10,7 @@
 #include "../../raytracer_amd/host/RayCaster.h"
 #include "../../raytracer_amd/host/ShadeInfoAdapter.h"
 #include "../../raytracer_amd/host/Denoiser.h"
+#include "../../raytracer_amd/host/SceneLoader.h"
 
 using namespace rtamd;
 
@@ -314,6 +315,46 @@ int main() {
         }
         CHECK(badCount == 0 && badPix == 0, "progressive preview: %d sample counts off, %d pixels differ", badCount, badPix);
         CHECK(imgP.GetNumRenderedPixels() >= (int)np, "progressive preview advances the rendered-pixel counter");
+    }
+
+    // scene ingest -> GPU -> image: an XML scene with an OBJ mesh, a sphere and a plane, rendered through RayCaster
+    {
+        FILE* f = std::fopen("/tmp/rtamd_scene.xml", "w");
+        std::fputs("<xml><scene>"
+                   "<object type='obj' name='rtamd_tri.obj' material='red'><translate x='0' y='0.5' z='0'/></object>"
+                   "<object type='sphere' name='ball' material='mirror'><scale value='0.6'/><translate x='1.4' y='0.6' z='0'/></object>"
+                   "<object type='plane' name='floor' material='white'><rotate angle='-90' x='1'/><scale value='5'/></object>"
+                   "<material type='blinn' name='red'><diffuse r='0.8' g='0.1' b='0.1'/><specular value='0.2'/></material>"
+                   "<material type='blinn' name='mirror'><diffuse value='0.05'/><reflection value='0.9'/><glossiness value='2000'/></material>"
+                   "<material type='blinn' name='white'><diffuse value='0.7'/><specular value='0'/></material>"
+                   "<light type='point' name='l'><intensity value='30'/><position x='2' y='5' z='3'/><size value='0.5'/></light>"
+                   "<environment r='0.2' g='0.25' b='0.3'/>"
+                   "</scene><camera><position x='0.5' y='1.5' z='5'/><target x='0.5' y='0.5' z='0'/><up x='0' y='1' z='0'/>"
+                   "<fov value='40'/><width value='80'/><height value='48'/></camera></xml>", f);
+        std::fclose(f);
+        f = std::fopen("/tmp/rtamd_tri.obj", "w");
+        std::fputs("v -1 0 0\nv 0 0 0\nv -0.5 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\n", f);
+        std::fclose(f);
+        SceneLoader loader;
+        LoadedScene ls;
+        std::string err;
+        CHECK(loader.Load("/tmp/rtamd_scene.xml", ls, err), "SceneLoader: %s", err.c_str());
+        RayCaster rcx(&ls.scene, &ls.camera);
+        rcx.sampling.minSamples = rcx.sampling.maxSamples = 4;
+        rcx.sampling.maxBounces = 4;
+        RenderImage imx;
+        imx.Init(ls.camera.imgWidth, ls.camera.imgHeight);
+        rcx.CastRays(imx);
+        double meanx = 0;
+        for (int i = 0; i < 80 * 48; ++i) meanx += imx.GetLinearPixels()[i].r + imx.GetLinearPixels()[i].g + imx.GetLinearPixels()[i].b;
+        CHECK(meanx / (80 * 48 * 3) > 0.02, "loaded scene renders (mean %.4f)", meanx / (80 * 48 * 3));
+        HitInfo hs;
+        hs.Init();
+        Ray toBall(ls.camera.pos, (Vec3f(1.4f, 0.6f, 0.0f) - ls.camera.pos).GetNormalized());
+        CHECK(IntersectNode(&ls.scene.rootNode, toBall, hs, HIT_FRONT) && dynamic_cast<const Sphere*>(hs.node->GetNodeObj()), "ray to the sphere hits it");
+        const float expectT = (Vec3f(1.4f, 0.6f, 0.0f) - ls.camera.pos).Length() - 0.6f;
+        CHECK(std::fabs(hs.z - expectT) < 1e-4f, "sphere hit distance %.6f vs %.6f", hs.z, expectT);
+        ReleaseGpuScenes();
     }
 
     // Stop() from another thread ends a long render early
