@@ -172,6 +172,15 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # PyTorch wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, no soname version) next to the system one
+    # this library links (libamdhip64.so.7). Both can live in one process, but only when torch's libraries are mapped
+    # before the system runtime initialises the GPU; the other order leaves torch with "No HIP GPUs are available".
+    # Python callers of this package use torch for device buffers, so map it first when it is installed.
+    if not os.environ.get("RTX_AMD_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(p):
         raise RuntimeError(
             f"{p} not found: the HIP library is the only compute path of raytracer_amd; build it with "
