@@ -54,5 +54,5 @@ struct PathPool {
     int* pixelsNext;
     float4* statSum;        // sum rgb, w = bits(n)
     float4* statSum2;       // sum of squares rgb, w = running bestZ
-    unsigned long long* rayCounters;  // [0] shadow hops
+    unsigned long long* rayCounters;  // [0] shadow hops, [1] closest-hit rays of tail_kernel
 };

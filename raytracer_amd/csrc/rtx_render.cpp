@@ -6,6 +6,7 @@
 #include "pathstate.h"
 #include "photon.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 struct PathPoolHost {
@@ -265,6 +266,9 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     RTX_HIP(hipMemsetAsync(pool.qB.ctl, 0, SEGQ_WORDS * sizeof(uint32_t), st));
     RTX_HIP(hipMemsetAsync(pool.qS.ctl, 0, SEGQ_WORDS * sizeof(uint32_t), st));
     const uint32_t shadowMult = (uint32_t)std::max(1, s->dev.n_lights);
+    uint32_t tailMax = std::min<uint32_t>(RTX_TAIL_MAX_PATHS, (uint32_t)s->cfg.gridBlocks * TRAV_BLOCK);
+    if (const char* e = std::getenv("RTX_AMD_TAIL_PATHS")) tailMax = std::min<uint32_t>(tailMax, (uint32_t)std::atol(e));   // 0 disables
+    if (s->cfg.counting) tailMax = 0;   // node / triangle tallies exist in the counting build of extend_kernel only
 
     s->cancel.store(0);
     PassTimers tm{ph};
@@ -310,6 +314,14 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 std::swap(qin, qout);
                 std::swap(sqIn, sqOut);
                 n = cnt[0];
+                if (n > 0 && n <= tailMax && bounce + 1 < rp->max_bounces) {
+                    // few paths left: one kernel walks them to their ends (tail_kernel)
+                    tm.begin(2, st);
+                    launch_tail(s->dev, s->cfg, dc, pool, pm, sqIn, qin, n, bounce + 1, rp->max_bounces, rp->seed, sBase, Sp, curPixels,
+                                s->hasMicrofacet);
+                    tm.end(st);
+                    n = 0;
+                }
                 if (tm.spans.size() > 2048) {
                     RTX_HIP(hipStreamSynchronize(st));
                     tm.flush();
@@ -343,9 +355,10 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     (void)hipEventElapsedTime(&total, evTotal0, evTotal1);
     (void)hipEventDestroy(evTotal0);
     (void)hipEventDestroy(evTotal1);
-    unsigned long long hops = 0;
-    RTX_HIP(hipMemcpy(&hops, pool.rayCounters, sizeof(hops), hipMemcpyDeviceToHost));
-    out.rays_shadow = hops;
+    unsigned long long rc2[2] = {0, 0};   // [0] shadow hops, [1] closest-hit rays traced inside tail_kernel
+    RTX_HIP(hipMemcpy(rc2, pool.rayCounters, sizeof(rc2), hipMemcpyDeviceToHost));
+    out.rays_shadow = rc2[0];
+    out.rays_bounce += rc2[1];
     out.extend_ms = tm.ms[0];
     out.shadow_ms = tm.ms[1];
     out.shade_ms = tm.ms[2];

@@ -1,0 +1,281 @@
+// The per-vertex body of the path loop (one bounce of TracePath, reference RayTracer/RayCaster.cpp:359-567), shared by
+// shade_kernel (kernels_path.hip: one launch per bounce, NEE visibility through the shadow queue) and tail_kernel
+// (kernels_tail.hip: the last few paths of a pass walked to their ends inside one kernel).
+#pragma once
+#include "kernels.h"
+#include "pathstate.h"
+#include "bsdf.h"
+#include "shadow.h"
+#include "photon_gather.h"
+#include "segqueue.h"
+
+// ---- shade ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f3 apply_absorption(f3 c, f3 absorption, float dist) {   // RayCaster.cpp:281-301
+    if (dist <= 0.0f) return c;
+    if (absorption.x == 0.0f && absorption.y == 0.0f && absorption.z == 0.0f) return c;
+    const float ar = expf(-fmaxf(0.0f, absorption.x) * dist);
+    const float ag = expf(-fmaxf(0.0f, absorption.y) * dist);
+    const float ab = expf(-fmaxf(0.0f, absorption.z) * dist);
+    return mk3(fminf(c.x, c.x * ar), fminf(c.y, c.y * ag), fminf(c.z, c.z * ab));
+}
+__device__ __forceinline__ void dir_to_screen_uv(const DevCamera& cam, f3 dir, float& u, float& v) {   // :303-330
+    const f3 f = ld3(cam.f), r = ld3(cam.r), uvec = ld3(cam.u);
+    float dz = dot3(dir, f);
+    if (fabsf(dz) < 1e-6f) dz = (dz >= 0.0f) ? 1e-6f : -1e-6f;
+    const float sx = dot3(dir, r) / dz;
+    const float sy = dot3(dir, uvec) / dz;
+    const float fovRad = cam.fov * PI_F / 180.0f;
+    const float halfY = tanf(0.5f * fovRad);
+    const float aspect = (cam.H > 0) ? (float)cam.W / (float)cam.H : 1.0f;
+    const float halfX = halfY * aspect;
+    const float ndcX = sx / halfX;
+    const float ndcY = sy / halfY;
+    u = (ndcX + 1.0f) * 0.5f;
+    v = (1.0f - ndcY) * 0.5f;
+    u = u - floorf(u);
+    v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+}
+__device__ __forceinline__ float power_heuristic(float pdfA, float pdfB) {   // :102-106
+    const float a = pdfA * pdfA;
+    const float b = pdfB * pdfB;
+    return a / (a + b);
+}
+__device__ __forceinline__ bool has_map_or_value(const float* c, int tex) {   // :333-337
+    return tex >= 0 || c[0] != 0.0f || c[1] != 0.0f || c[2] != 0.0f;
+}
+
+
+// One bounce of TracePath (RayCaster.cpp:359-567) for every path in queueIn. Paths that continue are appended to
+// queueOut; NEE shadow segments are appended to the shadow queue; their results are folded in by resolve_kernel.
+// One vertex of one path: returns true when the path continues (its next ray is in pool.rays[slot]).
+// MICRO: the scene holds MtlMicrofacet materials (a second BSDF in the kernel; scenes without them run the leaner one).
+// TAIL: the caller is tail_kernel, which walks a path to its end inside one kernel: NEE visibility is traced on the
+// spot (st, hops) and folded into L here, in the order resolve_kernel would add it; nothing goes to the queues.
+template <bool MICRO, bool TAIL>
+__device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm,
+                                           uint32_t slot, const RayT& ray, const HitT& h, int bounce, int maxBounces,
+                                           unsigned long long seed, int sBase, int S, const int* __restrict__ pixels,
+                                           const SegQ& qShadow, TravStack st, uint32_t& hops) {
+    bool alive = false;
+    const uint32_t cap = pool.capacity;
+    const uint32_t shadowMult = (uint32_t)max(1, sc.n_lights);
+    {
+        float4 L4 = pool.L[slot];
+        float4 b4 = pool.beta[slot];
+        float4 m4 = pool.medium[slot];
+        f3 L = mk3(L4.x, L4.y, L4.z);
+        f3 beta = mk3(b4.x, b4.y, b4.z);
+        float lastPdf = b4.w;
+        uint32_t flags = __float_as_uint(m4.w);
+        f3 mediumAbs = mk3(m4.x, m4.y, m4.z);
+        const f3 rdir = mk3(ray.dx, ray.dy, ray.dz), rorg = mk3(ray.ox, ray.oy, ray.oz);
+        // pixel / sample of this slot -> RNG key
+        const uint32_t lane64 = slot & 63u, cs = slot >> 6;
+        const int pix = pixels[(cs / (uint32_t)S) * 64u + lane64];
+        const int sIdx = sBase + (int)(cs % (uint32_t)S);
+        bool pending = false;   // NEE of this bounce to be resolved
+
+        do {
+            if (h.slot == -1) {
+                // ---- miss: backplate / environment (RayCaster.cpp:362-382) ----
+                const f3 nd = normalized3(rdir);
+                float uEnv = 0.0f, vEnv = 0.0f;
+                dir_to_screen_uv(cam, nd, uEnv, vEnv);
+                const bool hasBackground = has_map_or_value(sc.bg, sc.bg_tex);
+                const bool hasEnvironment = has_map_or_value(sc.env, sc.env_tex);
+                const f3 backplate = hasBackground ? eval_tc(sc, sc.bg, sc.bg_tex, mk3(uEnv, vEnv, 0.0f)) : mk3(0.0f);
+                f3 envLight = mk3(0.0f);
+                if (hasEnvironment) envLight = sc.env_tex >= 0 ? ld3(sc.env) * tex_eval_env(sc, sc.env_tex, nd) : ld3(sc.env);
+                const f3 bgEmit = (hasBackground && sc.bg_emission > 0.0f) ? backplate * sc.bg_emission : mk3(0.0f);
+                if (bounce == 0) {
+                    const f3 vis = hasBackground ? backplate : envLight;
+                    L = L + beta * (vis + bgEmit);
+                } else {
+                    L = L + beta * (envLight + bgEmit);
+                }
+                break;
+            }
+            SurfHit sh;
+            if (h.slot >= 0) resolve_triangle(sc, ray, h, sh);
+            else resolve_light(sc, ray, h, sh);
+            const float hitDist = len3(sh.p - rorg);
+            if ((flags & PF_INSIDE_MEDIUM) && hitDist > 0.0f) beta = apply_absorption(beta, mediumAbs, hitDist);
+
+            const DevMaterial* mtl = nullptr;
+            if (sh.obj >= 0) {
+                const int mi = sc.objs[sh.obj].material;
+                if (mi >= 0) mtl = &sc.mtls[mi];
+            }
+            if (mtl) apply_bump(sc, *mtl, sh);
+            SampCtx sx;
+            sx.P = sh.p;
+            sx.V = -normalized3(rdir);
+            sx.N = sh.N;
+            sx.GN = sh.GN;
+            sx.uvw = sh.uvw;
+            sx.front = sh.front;
+            sx.key = rng_key(seed, (uint32_t)pix, (uint32_t)sIdx);
+            sx.stream = (uint32_t)bounce;
+
+            const bool micro = MICRO && mtl && mtl->type == RTX_MTL_MICROFACET;
+            if (bounce == 0) {   // :401-407, GetDiffuseAlbedo :135-138
+                L4.w = hitDist;
+                const f3 alb = (mtl && !micro) ? eval_tc(sc, mtl->kd, mtl->kd_tex, sx.uvw) : mk3(0.5f);
+                const f3 fn = safe_normalize3(sh.GN);
+                pool.albedo[slot] = make_float4(alb.x, alb.y, alb.z, 1.0f);
+                pool.normal[slot] = make_float4(fn.x, fn.y, fn.z, 1.0f);
+            }
+
+            if (sh.light >= 0) {   // :410-439
+                const DevLight& light = sc.lights[sh.light];
+                const f3 emitted = ld3(light.intensity) / (PI_F * light.size * light.size);
+                float lightPdfSA = 0.0f;
+                if (flags & PF_HAS_PREV) {
+                    const float4 pp = pool.prevP[slot];
+                    DirInfo li;
+                    light_get_sample_info(light, mk3(pp.x, pp.y, pp.z), rdir, li);
+                    lightPdfSA = li.prob;
+                    if (light.size > 0.0f) {
+                        const float cosLight = fmaxf(0.0f, dot3(-sh.N, safe_normalize3(rdir)));
+                        const float dist2 = li.dist * li.dist;
+                        if (cosLight > 1e-6f && dist2 > 0.0f) lightPdfSA = li.prob * dist2 / cosLight;
+                        else lightPdfSA = 0.0f;
+                    } else
+                        lightPdfSA = 0.0f;
+                }
+                const float w = ((flags & PF_LAST_DELTA) || lightPdfSA <= 0.0f) ? 1.0f : power_heuristic(lastPdf, lightPdfSA);
+                L = L + beta * emitted * w;
+                break;
+            }
+            if (!mtl) break;
+
+            const f3 emission = micro ? mk3(0.0f) : eval_tc(sc, mtl->ke, mtl->ke_tex, sx.uvw);   // :445-446, GetEmission :158-161
+            if (max3c(emission) > 0.0f) L = L + beta * emission;
+
+            PhongCtx ctx;
+            MicroCtx mctx;
+            if (micro) mctx = build_micro_ctx(sc, *mtl, sx);
+            else ctx = build_phong_ctx(sc, *mtl, sx);
+            const bool phong = mtl->type == RTX_MTL_PHONG;
+
+            // ---- next event estimation: contributions now, visibility by the shadow kernel (:456-503) ----
+            const bool photonSurface = mtl_is_photon_surface(*mtl);
+            const bool wantCaustic = pm.n > 0 && photonSurface;
+            f3 tailDirect = mk3(0.0f);
+            float tailMaxVis = 0.0f;
+            for (int l = 0; l < sc.n_lights; ++l) {
+                const DevLight& light = sc.lights[l];
+                f3 ldir;
+                DirInfo li;
+                float4 contrib = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+                const float u1 = sx.rnd(DIM_LIGHT0 + 2 * l), u2 = sx.rnd(DIM_LIGHT0 + 2 * l + 1);
+                if (light_generate_sample(light, sx.P, u1, u2, ldir, li) && li.prob > 0.0f && max3c(li.mult) > 0.0f) {
+                    const float shadowMax = (li.dist > 0.0f && li.dist < RTX_BIG * 0.5f) ? li.dist : RTX_BIG;
+                    DirInfo bs;
+                    if (micro) evaluate_microfacet(mctx, sx, safe_normalize3(ldir), bs);
+                    else evaluate_phong_blinn(ctx, phong, sx, safe_normalize3(ldir), bs);
+                    f3 c = mk3(0.0f);
+                    if (bs.prob > 0.0f && max3c(bs.mult) > 0.0f) {
+                        if (light.size > 0.0f) {
+                            const float dist = li.dist;
+                            const float cosLight = light_cos_for_nee(light, sh.p, safe_normalize3(ldir));
+                            const float pdfSolidAngle = (cosLight > 1e-6f && dist > 1e-6f) ? li.prob * dist * dist / cosLight : 0.0f;
+                            if (pdfSolidAngle > 0.0f) {
+                                const float w = power_heuristic(pdfSolidAngle, bs.prob);
+                                const float G = 1.0f / fmaxf(1e-6f, dist * dist);
+                                c = li.mult * bs.mult * G * (w / fmaxf(1e-6f, li.prob));
+                            }
+                        } else {
+                            const float w = power_heuristic(li.prob, bs.prob);
+                            c = li.mult * bs.mult * (w / fmaxf(1e-4f, li.prob));
+                        }
+                    }
+                    // the shadow segment is needed when it can contribute, or when its visibility scales the
+                    // caustic term (:468, :518)
+                    if (max3c(c) > 0.0f || wantCaustic) {
+                        contrib = make_float4(c.x, c.y, c.z, 0.0f);
+                        pending = true;
+                        const f3 so = offset_point(sh.p, sx.GN, ldir);
+                        const f3 sd = safe_normalize3(ldir);
+                        if (TAIL) {
+                            uint32_t nc = 0, tc = 0;
+                            const float T = visible_chain_from<false>(sc, so, sd, shadowMax, bounce <= 8, st, &hops, &nc, &tc);
+                            tailMaxVis = fmaxf(tailMaxVis, T);
+                            if (T > 0.0f) tailDirect = tailDirect + c * T;
+                        } else {
+                            // wave-wide append of the lanes that reach this point (ballot counts active lanes only)
+                            const uint32_t qs = segq_append(qShadow, true, shadowMult);
+                            pool.shadowQ[2 * (size_t)qs] = make_float4(so.x, so.y, so.z, shadowMax);
+                            pool.shadowQ[2 * (size_t)qs + 1] = make_float4(sd.x, sd.y, sd.z, __uint_as_float(slot * 8u + (uint32_t)l));
+                        }
+                    }
+                }
+                if (!TAIL) pool.nee[(size_t)l * cap + slot] = contrib;
+            }
+            if (TAIL) {
+                if (max3c(tailDirect) > 0.0f) L = L + beta * tailDirect;   // resolve_kernel, RayCaster.cpp:470-503
+            } else if (pending)
+                pool.pendBeta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
+
+            if (pm.n > 0) {   // :508-522 (scaled by the visibility in resolve_kernel)
+                float4 cz = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (photonSurface) {
+                    f3 irrad = estimate_irradiance(pm, sh.p, sh.N);
+                    if (max3c(irrad) > 0.0f) {
+                        const f3 kd = micro ? mk3(0.5f) : eval_tc(sc, mtl->kd, mtl->kd_tex, sx.uvw);
+                        irrad = irrad * 0.1f;   // kCausticBoost
+                        const f3 t = kd * (1.0f / PI_F) * irrad;
+                        cz = make_float4(t.x, t.y, t.z, 1.0f);
+                        if (TAIL) L = L + beta * (t * (0.1f + 0.9f * tailMaxVis));   // resolve_kernel, RayCaster.cpp:518-520
+                        else if (!pending) pool.pendBeta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
+                        pending = true;
+                    }
+                }
+                if (!TAIL) pool.caustic[slot] = cz;
+            }
+
+            // ---- BSDF sampling for the next bounce (:525-566) ----
+            f3 nextDir;
+            DirInfo bsd;
+            if (micro ? !sample_microfacet(mctx, sx, nextDir, bsd) : !sample_phong_blinn(ctx, phong, sx, nextDir, bsd)) break;
+            if (bsd.prob <= 0.0f || max3c(bsd.mult) <= 0.0f) break;
+            const float pdfThroughput = fmaxf(1e-4f, bsd.prob);
+            beta = beta * (bsd.mult / pdfThroughput);
+            lastPdf = bsd.prob;
+            flags = (flags & ~PF_LAST_DELTA) | (bsd.dist < 0.0f ? PF_LAST_DELTA : 0u);
+            pool.prevP[slot] = make_float4(sh.p.x, sh.p.y, sh.p.z, 0.0f);
+            flags |= PF_HAS_PREV;
+            if (bsd.lobe & LOBE_TRANSMISSION) {
+                if (sx.front) {
+                    flags |= PF_INSIDE_MEDIUM;
+                    mediumAbs = ld3(mtl->absorption);
+                } else {
+                    flags &= ~PF_INSIDE_MEDIUM;
+                    mediumAbs = mk3(0.0f);
+                }
+            }
+            if (bounce >= 5) {
+                float q = clamp01f(max3c(beta));
+                q = fmaxf(q, 0.05f);
+                if (sx.rnd(DIM_RR) > q) break;
+                beta = beta * (1.0f / q);
+            }
+            if (bounce + 1 >= maxBounces) break;
+            const f3 no = offset_point(sh.p, sx.GN, nextDir);
+            const f3 nd = safe_normalize3(nextDir);
+            pool.rays[2 * (size_t)slot] = make_float4(no.x, no.y, no.z, RTX_BIG);
+            pool.rays[2 * (size_t)slot + 1] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+            alive = true;
+        } while (false);
+
+        pool.L[slot] = make_float4(L.x, L.y, L.z, L4.w);
+        pool.beta[slot] = make_float4(beta.x, beta.y, beta.z, lastPdf);
+        pool.medium[slot] = make_float4(mediumAbs.x, mediumAbs.y, mediumAbs.z, __uint_as_float(flags));
+        if (!TAIL && !pending) {
+            // mark "nothing to resolve" for resolve_kernel
+            pool.pendBeta[slot] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+        }
+    }
+    return alive;
+}
+
