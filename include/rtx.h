@@ -172,7 +172,14 @@ typedef struct {
     int rank, world;               /* tile sharding: this call renders tiles t with t % world == rank  */
     int samples_per_pass;          /* path-pool sizing: samples per pixel traced per wavefront pass; 0 = auto */
     int use_photons;               /* gather the caustics map when a photon handle is given           */
+    int shading_mode;              /* RTX_SHADING_PATH (0, the reference's default build) or RTX_SHADING_LEGACY:
+                                    * the SHADING_USE_LEGACY=1 build (ShadingConfig.h:7-13): TraceLegacy
+                                    * (RayCaster.cpp:579-631) -> Shade() of Shading_Legacy.cpp through
+                                    * ShadeInfoAdapter::TraceShadowRay / TraceSecondaryRay; with a photon handle
+                                    * and use_photons it gathers the caustics AND the global map (:434-444)    */
 } rtx_render_params;
+#define RTX_SHADING_PATH 0
+#define RTX_SHADING_LEGACY 1
 
 /* Film accumulators, caller-provided DEVICE memory, all width*height, row-major y*W+x
  * (per-thread buffers of RayCaster.cpp:1168-1171). The caller zeroes accum/count and fills z with

@@ -174,7 +174,7 @@ int orc_trace_samples(void* s, const rtx_camera* cam, const rtx_render_params* r
         float jx = std::fmod(halton(sampleIndex, 2) + shx, 1.0f) - 0.5f;
         float jy = std::fmod(halton(sampleIndex, 3) + shy, 1.0f) - 0.5f;
         Ray r = generate_ray(c, float(x) + 0.5f + jx, float(y) + 0.5f + jy, sampleIndex);
-        PathResult pr = trace_path(*sc, c, r, x, y, sIdx, (PhotonMapper*)photons, rp->max_bounces, rp->seed, nullptr);
+        PathResult pr = trace_radiance(*sc, c, r, x, y, sIdx, (PhotonMapper*)photons, *rp, nullptr);
         out[4 * i] = pr.radiance.x; out[4 * i + 1] = pr.radiance.y; out[4 * i + 2] = pr.radiance.z;
         out[4 * i + 3] = pr.primaryDist;
     }

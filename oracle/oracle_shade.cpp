@@ -979,6 +979,24 @@ static inline float power_heuristic(float pdfA, float pdfB) {  // RayCaster.cpp:
 
 static inline bool has_map_or_value(V3 c, int tex) { return tex >= 0 || c.x != 0.0f || c.y != 0.0f || c.z != 0.0f; }
 
+// the miss branch of TracePath (RayCaster.cpp:362-382) and of TraceLegacy (:583-593, camera rays only)
+V3 miss_radiance(const Scene& scene, const Camera& camera, V3 nd, bool cameraRay) {
+    float uEnv = 0.0f, vEnv = 0.0f;
+    dir_to_screen_uv(camera, nd, uEnv, vEnv);
+    const bool hasBackground = has_map_or_value(scene.bgColor, scene.bgTex);
+    const bool hasEnvironment = has_map_or_value(scene.envColor, scene.envTex);
+    float bgv[3] = {scene.bgColor.x, scene.bgColor.y, scene.bgColor.z};
+    const V3 backplate = hasBackground ? scene.eval_tc(bgv, scene.bgTex, V3(uEnv, vEnv, 0.0f)) : V3(0, 0, 0);
+    V3 envLight(0, 0, 0);
+    if (hasEnvironment) envLight = scene.envTex >= 0 ? scene.envColor * scene.texmaps[scene.envTex].eval_env(nd) : scene.envColor;
+    const V3 bgEmit = (hasBackground && scene.bgEmission > 0.0f) ? backplate * scene.bgEmission : V3(0, 0, 0);
+    if (cameraRay) {
+        const V3 vis = hasBackground ? backplate : envLight;
+        return vis + bgEmit;
+    }
+    return envLight + bgEmit;
+}
+
 // RayCaster.cpp:339-574
 PathResult trace_path(const Scene& scene, const Camera& camera, Ray ray, int px, int py, int sampleIdx,
                       const PhotonMapper* mapper, int maxBounces, uint64_t seed, PathCounters* pc) {
@@ -1003,22 +1021,7 @@ PathResult trace_path(const Scene& scene, const Camera& camera, Ray ray, int px,
         if (pc) (bounce == 0 ? pc->primary : pc->bounce)++;
         bool hitGeom = scene.intersect_with_lights(ray, h, RTX_HIT_FRONT_AND_BACK);
         if (!hitGeom) {
-            float uEnv = 0.0f, vEnv = 0.0f;
-            V3 nd = normalized(ray.dir);
-            dir_to_screen_uv(camera, nd, uEnv, vEnv);
-            const bool hasBackground = has_map_or_value(scene.bgColor, scene.bgTex);
-            const bool hasEnvironment = has_map_or_value(scene.envColor, scene.envTex);
-            float bgv[3] = {scene.bgColor.x, scene.bgColor.y, scene.bgColor.z};
-            const V3 backplate = hasBackground ? scene.eval_tc(bgv, scene.bgTex, V3(uEnv, vEnv, 0.0f)) : V3(0, 0, 0);
-            V3 envLight(0, 0, 0);
-            if (hasEnvironment) envLight = scene.envTex >= 0 ? scene.envColor * scene.texmaps[scene.envTex].eval_env(nd) : scene.envColor;
-            const V3 bgEmit = (hasBackground && scene.bgEmission > 0.0f) ? backplate * scene.bgEmission : V3(0, 0, 0);
-            if (bounce == 0) {
-                const V3 vis = hasBackground ? backplate : envLight;
-                L = L + beta * (vis + bgEmit);
-            } else {
-                L = L + beta * (envLight + bgEmit);
-            }
+            L = L + beta * miss_radiance(scene, camera, normalized(ray.dir), bounce == 0);
             break;
         }
         float hitDist = len(h.p - ray.p);
@@ -1150,6 +1153,13 @@ PathResult trace_path(const Scene& scene, const Camera& camera, Ray ray, int px,
     return PathResult{L, primaryDist, firstAlbedo, firstNormal, haveFirstHit};
 }
 
+// TraceRadiance (RayCaster.cpp:634-640): the compile-time SHADING_USE_LEGACY switch is rtx_render_params::shading_mode
+PathResult trace_radiance(const Scene& sc, const Camera& cam, Ray ray, int px, int py, int sampleIdx, const PhotonMapper* mapper,
+                          const rtx_render_params& rp, PathCounters* pc) {
+    if (rp.shading_mode == RTX_SHADING_LEGACY) return trace_legacy(sc, cam, ray, px, py, sampleIdx, mapper, rp.seed, pc);
+    return trace_path(sc, cam, ray, px, py, sampleIdx, mapper, rp.max_bounces, rp.seed, pc);
+}
+
 // ---- film / RenderBucket ---------------------------------------------------------------------------------
 void Film::init(int w, int h) {
     W = w;
@@ -1202,7 +1212,7 @@ static void take_sample(const PixelCtx& c, int x, int y, int s, float shiftX, fl
     float samplePosX = float(x) + 0.5f + jitterX;
     float samplePosY = float(y) + 0.5f + jitterY;
     Ray ray = generate_ray(*c.cam, samplePosX, samplePosY, sampleIndex);
-    PathResult pr = trace_path(*c.sc, *c.cam, ray, x, y, s, c.mapper, c.rp->max_bounces, c.rp->seed, c.pc);
+    PathResult pr = trace_radiance(*c.sc, *c.cam, ray, x, y, s, c.mapper, *c.rp, c.pc);
     V3 col = pr.radiance;
     if (pr.primaryDist < bestZ) bestZ = pr.primaryDist;
     Film& f = *c.film;

@@ -114,6 +114,15 @@ struct PathCounters {
 PathResult trace_path(const Scene& sc, const Camera& cam, Ray ray, int px, int py, int sampleIdx,
                       const PhotonMapper* mapper, int maxBounces, uint64_t seed, PathCounters* pc);
 
+V3 miss_radiance(const Scene& sc, const Camera& cam, V3 nd, bool cameraRay);
+V3 mtl_diffuse_albedo(const Scene& sc, const Material& m, const SInfo& s);
+bool mtl_is_photon_surface(const Material& m);
+// legacy shading mode (oracle_legacy.cpp): TraceLegacy, RayCaster.cpp:579-631
+PathResult trace_legacy(const Scene& sc, const Camera& cam, Ray ray, int px, int py, int sampleIdx, const PhotonMapper* mapper,
+                        uint64_t seed, PathCounters* pc);
+PathResult trace_radiance(const Scene& sc, const Camera& cam, Ray ray, int px, int py, int sampleIdx, const PhotonMapper* mapper,
+                          const rtx_render_params& rp, PathCounters* pc);
+
 struct Film {
     int W = 0, H = 0;
     std::vector<float> accum;  // 4 per pixel

@@ -72,11 +72,14 @@ class Hit(C.Structure):
                 ("front", C.c_int), ("light", C.c_int)]
 
 
+SHADING_PATH, SHADING_LEGACY = 0, 1
+
+
 class RenderParams(C.Structure):
     _fields_ = [("spp_min", C.c_int), ("spp_max", C.c_int), ("index_stride", C.c_int), ("ci_halfwidth", C.c_float),
                 ("filter_type", C.c_int), ("filter_radius", C.c_float), ("max_bounces", C.c_int),
                 ("seed", C.c_uint64), ("tile_size", C.c_int), ("rank", C.c_int), ("world", C.c_int),
-                ("samples_per_pass", C.c_int), ("use_photons", C.c_int)]
+                ("samples_per_pass", C.c_int), ("use_photons", C.c_int), ("shading_mode", C.c_int)]
 
 
 class Film(C.Structure):

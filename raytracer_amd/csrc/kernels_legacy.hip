@@ -1,0 +1,533 @@
+// Legacy shading mode on gfx950: the reference's SHADING_USE_LEGACY=1 build (RayTracer/ShadingConfig.h:7-13), i.e.
+// TraceLegacy (RayTracer/RayCaster.cpp:579-631) -> MtlBlinn/MtlPhong/MtlMicrofacet::Shade
+// (RayTracer/Shading_Legacy.cpp:366-694) with PointLight::Illuminate (:115-210) and the shadow / secondary rays of
+// ShadeInfoAdapter (RayTracer/ShadeInfoAdapter.h:49-231).
+//
+// The reference evaluates a recursion tree per camera sample: every Shade() may call TraceSecondaryRay up to three
+// times (diffuse bounce, glossy reflection, glossy refraction), at most 5 levels deep (CanBounce, :44). The tree is
+// LINEAR in the colours its calls return - every use is `colour * weight` with a weight known at the call, and the
+// Beer-Lambert factor of a refraction ray (:359) needs only that ray's own hit distance - so it is evaluated here
+// without recursion: a pending call is a record {biased ray, weight of its colour in the sample, absorption, RNG node,
+// depth}; one lane per camera sample pops records from a small private stack, traces them, adds weight x (local
+// terms) to the sample and pushes the calls of the Shade() it reached. Sums are formed in a different order than the
+// recursion's (parity with the oracle is a tolerance, as for the path mode).
+//
+// Random numbers: Shade() number `node` of the tree (root 0; children 3*node+1 diffuse, +2 reflection, +3 refraction)
+// draws from the counter generator keyed (pixel, sample) x node x draw slot, identically in oracle/oracle_legacy.cpp.
+#include "shade_body.h"
+
+#define LG_MAX_BOUNCES 5        // ShadeInfoAdapter::kMaxSpecularBounces (:245)
+#define LG_STACK 12             // 3 calls at depth 0, then 2 left + 3 new per level down to depth 4: 11
+#define LG_DIM_REFL 32          // draw slots of SampleGlossy for the reflection / refraction ray
+#define LG_DIM_REFR 34
+
+struct LgCall {                 // one pending TraceSecondaryRay call
+    f3 o, d;                    // biased origin, unit direction (:99-112)
+    f3 w;                       // weight of the returned colour in the sample's radiance
+    f3 absorb;                  // Beer-Lambert coefficients applied over the call's `dist` (refraction rays), else 0
+    uint32_t node;              // RNG node of the Shade() the call leads to
+    uint32_t bounceDepth;       // bounce of that Shade() | diffuse depth of the caller << 8
+};
+
+struct LgState {
+    f3 L;
+    uint32_t sp, rays, shadows;
+    LgCall stack[LG_STACK];
+};
+
+struct LgScene {
+    const DevScene& sc;
+    const DevPhotonMap& pmGlobal;
+    const DevPhotonMap& pmCaustic;
+    TravStack st;
+};
+
+__device__ __forceinline__ f3 clamp01_3(f3 c) { return mk3(clamp01f(c.x), clamp01f(c.y), clamp01f(c.z)); }
+
+// Shading_Legacy.cpp:321-329 as a factor on the colour
+__device__ __forceinline__ f3 lg_absorption_factor(f3 absorption, float dist) {
+    if (dist <= 0.0f) return mk3(1.0f);
+    if (absorption.x == 0.0f && absorption.y == 0.0f && absorption.z == 0.0f) return mk3(1.0f);
+    return mk3(expf(-absorption.x * dist), expf(-absorption.y * dist), expf(-absorption.z * dist));
+}
+
+// PointLight::IntersectRay of the legacy build (Shading_Legacy.cpp:212-235): distance or -1
+__device__ __forceinline__ float lg_light_intersect(const DevLight& L, f3 o, f3 d) {
+    if (L.size <= 0.0f) return -1.0f;
+    const f3 toC = ld3(L.pos) - o;
+    const float tca = dot3(toC, d);
+    if (tca < 0.0f) return -1.0f;
+    const float d2 = len2_3(toC) - tca * tca;
+    if (d2 > L.size * L.size) return -1.0f;
+    const float thc = sqrtf(L.size * L.size - d2);
+    float t0 = tca - thc, t1 = tca + thc;
+    if (t0 > t1) {
+        const float t = t0;
+        t0 = t1;
+        t1 = t;
+    }
+    if (t0 < 0.0f) t0 = t1;
+    if (t0 < 0.0f) return -1.0f;
+    return t0;
+}
+
+// ShadeInfoAdapter::TraceShadowRay (:49-88): one closest hit from the biased origin; the receiver's own node is
+// ignored close to the origin, a finite segment is blocked only before the light.
+__device__ __forceinline__ float lg_trace_shadow(const LgScene& g, const SampCtx& sx, int obj, f3 dir, float tMax, LgState& S) {
+    const float Llen = len3(dir);
+    if (Llen < 1e-12f) return 1.0f;
+    const bool finiteSegment = tMax < RTX_BIG * 0.5f;
+    const float segLenWorld = finiteSegment ? Llen * tMax : RTX_BIG;
+    const f3 Ldir = dir / Llen;
+    const f3 N = sx.N;
+    const float nDotL = dot3(N, Ldir);
+    const float baseBias = 1e-4f;
+    const float nBias = baseBias * (1.0f + 2.0f * (1.0f - fabsf(nDotL)));
+    const float dBias = baseBias * 0.5f;
+    const f3 o = sx.P + ((nDotL >= 0.0f) ? N : -N) * nBias + Ldir * dBias;
+    const RayT r{o.x, o.y, o.z, Ldir.x, Ldir.y, Ldir.z, RTX_BIG};
+    uint32_t nc = 0, tc = 0;
+    S.shadows++;
+    const HitT h = traverse_closest<false>(g.sc, r, RTX_HIT_FRONT_AND_BACK, g.st, &nc, &tc);
+    if (h.slot < 0) return 1.0f;
+    f3 GN;
+    bool front;
+    int hobj;
+    triangle_gn(g.sc, r, h.slot, h.t, GN, front, hobj);
+    const float4 b = reinterpret_cast<const float4*>(g.sc.tris)[(size_t)h.slot * 3 + 1];
+    f3 hp = o + Ldir * h.t;
+    if (__float_as_uint(b.w) != 0u) {   // Sphere / Plane: the hit point comes back through the node transform
+        SurfHit sh;
+        resolve_triangle(g.sc, r, h, sh);
+        hp = sh.p;
+    }
+    const float dist = len3(hp - o);
+    if (hobj == obj && dist < (nBias + dBias) * 6.0f) return 1.0f;
+    if (!finiteSegment) return dist > 0.0f ? 0.0f : 1.0f;
+    const float allowance = nBias * 1.5f;
+    return (dist < segLenWorld - allowance) ? 0.0f : 1.0f;
+}
+
+// PointLight::Illuminate (Shading_Legacy.cpp:115-210). TraceShadowRay returns exactly 0 or 1, so the first cone sample
+// is always "unanimous" (:189) and the 2nd..4th samples of the adaptive loop are never taken: one shadow ray per light.
+__device__ __forceinline__ f3 lg_illuminate(const LgScene& g, const SampCtx& sx, int obj, const DevLight& light, int l, f3& dir, LgState& S) {
+    const f3 toC = ld3(light.pos) - sx.P;
+    const float distC = len3(toC);
+    if (distC < 1e-20f) {
+        dir = mk3(0.0f);
+        return mk3(0.0f);
+    }
+    const f3 L = toC / distC;
+    dir = L;
+    float atten = 1.0f;
+    if (light.attenuation > 0.0f) atten = 1.0f / ((light.attenuation * distC) * (light.attenuation * distC));
+    const f3 I = ld3(light.intensity);
+    if (light.size <= 0.0f) return I * lg_trace_shadow(g, sx, obj, toC, 1.0f, S) * atten;
+    f3 U, V;
+    build_onb(L, U, V);
+    const float jx = sx.rnd(DIM_LIGHT0 + 2 * l), jy = sx.rnd(DIM_LIGHT0 + 2 * l + 1);
+    float h2 = 0.5f + jx;                 // Halton(1, 2)
+    h2 -= floorf(h2);
+    float h3 = (1.0f / 3.0f) * 1.0f + jy;   // Halton(1, 3)
+    h3 -= floorf(h3);
+    const float gamma = asinf(light.size / distC);
+    const float cosTheta = 1.0f - h2 * (1.0f - cosf(gamma));
+    const float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
+    const float phi = 2.0f * PI_F * h3;
+    const f3 sampleDir = normalized3(U * cosf(phi) * sinTheta + V * sinf(phi) * sinTheta + L * cosTheta);
+    const float vis = lg_trace_shadow(g, sx, obj, sampleDir * distC, 1.0f, S);
+    const float avgVis = vis / 1.0f;
+    return I * avgVis * atten;
+}
+
+// FresnelExact (Shading_Legacy.cpp:296-318)
+__device__ __forceinline__ float lg_fresnel_exact(f3 I, f3 N, float ior) {
+    float cosi = fminf(fmaxf(dot3(I, N), -1.0f), 1.0f);
+    float etai = 1.0f, etat = ior;
+    if (cosi > 0.0f) {
+        etai = ior;
+        etat = 1.0f;
+    }
+    cosi = fabsf(cosi);
+    const float sint = etai / etat * sqrtf(fmaxf(0.0f, 1.0f - cosi * cosi));
+    if (sint >= 1.0f) return 1.0f;
+    const float cost = sqrtf(fmaxf(0.0f, 1.0f - sint * sint));
+    const float Rs = ((etat * cosi) - (etai * cost)) / ((etat * cosi) + (etai * cost));
+    const float Rp = ((etai * cosi) - (etat * cost)) / ((etai * cosi) + (etat * cost));
+    return clamp01f(0.5f * (Rs * Rs + Rp * Rp));
+}
+
+// The ray of a TraceSecondaryRay call (ShadeInfoAdapter.h:99-112) queued with the weight of its colour
+__device__ __forceinline__ void lg_push(LgState& S, const SampCtx& sx, f3 dir, f3 w, f3 absorb, uint32_t node, int bounce, int diffuseDepth) {
+    const float dlen = len3(dir);
+    if (dlen < 1e-20f) return;
+    if (w.x == 0.0f && w.y == 0.0f && w.z == 0.0f) return;   // its colour is multiplied by zero
+    if (S.sp >= LG_STACK) return;                              // cannot happen (see LG_STACK)
+    dir = dir / dlen;
+    const f3 N = sx.N;
+    const float nDotD = dot3(N, dir);
+    const float baseBias = 1e-4f;
+    const float nBias = baseBias * (1.0f + 2.0f * (1.0f - fabsf(nDotD)));
+    const float dBias = baseBias * 0.5f;
+    LgCall& c = S.stack[S.sp++];
+    c.o = sx.P + ((nDotD >= 0.0f) ? N : -N) * nBias + dir * dBias;
+    c.d = dir;
+    c.w = w;
+    c.absorb = absorb;
+    c.node = node;
+    c.bounceDepth = (uint32_t)bounce | ((uint32_t)diffuseDepth << 8);
+}
+
+// direction of SampleGlossy (Shading_Legacy.cpp:332-356), glossySamples = 1
+__device__ __forceinline__ f3 lg_glossy_dir(const SampCtx& sx, f3 axis, float alpha, bool isReflection, f3 V) {
+    f3 U, Vb;
+    build_onb(axis, U, Vb);
+    const uint32_t d0 = isReflection ? LG_DIM_REFL : LG_DIM_REFR;
+    const float u1 = sx.rnd(d0), u2 = sx.rnd(d0 + 1);
+    const float cosTheta = powf(u1, 1.0f / (alpha + 1.0f));
+    const float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
+    const float phi = 2.0f * PI_F * u2;
+    const f3 H = normalized3(U * cosf(phi) * sinTheta + Vb * sinf(phi) * sinTheta + axis * cosTheta);
+    const f3 dir = isReflection ? (2.0f * dot3(V, H) * H - V) : H;
+    return normalized3(dir);
+}
+
+// legacy GenerateSample: MtlBlinn :697-788, MtlPhong :790-874, MtlMicrofacet :876-897
+__device__ __forceinline__ bool lg_generate_sample(const DevScene& sc, const DevMaterial& m, const SampCtx& s, f3& dir, DirInfo& si) {
+    if (m.type == RTX_MTL_MICROFACET) {
+        const f3 N = normalized3(s.N);
+        f3 U, Vb;
+        build_onb(N, U, Vb);
+        const float u1 = s.rnd(DIM_U1), u2 = s.rnd(DIM_U2);
+        const float cosTheta = sqrtf(u1);
+        const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+        const float phi = 2.0f * PI_F * u2;
+        dir = U * (sinTheta * cosf(phi)) + Vb * (sinTheta * sinf(phi)) + N * cosTheta;
+        si.mult = eval_tc(sc, m.kd, m.kd_tex, s.uvw);
+        si.prob = cosTheta / PI_F;
+        si.lobe = LOBE_DIFFUSE;
+        return true;
+    }
+    const bool phong = m.type == RTX_MTL_PHONG;
+    f3 N = normalized3(s.N);
+    if (!s.front) N = -N;
+    const f3 V = normalized3(s.V);
+    const float u1 = s.rnd(DIM_U1), u2 = s.rnd(DIM_U2);
+    const f3 diff = eval_tc(sc, m.kd, m.kd_tex, s.uvw);
+    const f3 refl = eval_tc(sc, m.kr, m.kr_tex, s.uvw);
+    const f3 refr = eval_tc(sc, m.kt, m.kt_tex, s.uvw);
+    const float diffWeight = diff.x + diff.y + diff.z, reflWeight = refl.x + refl.y + refl.z, refrWeight = refr.x + refr.y + refr.z;
+    const float total = diffWeight + reflWeight + refrWeight;
+    if (total < 1e-6f) return false;
+    const float pick = s.rnd(DIM_LOBE) * total;
+    const float alpha = m.gloss;
+    if (pick < diffWeight) {
+        f3 U, Vb;
+        build_onb(N, U, Vb);
+        const float cosTheta = sqrtf(u1);
+        const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+        const float phi = 2.0f * PI_F * u2;
+        dir = U * (sinTheta * cosf(phi)) + Vb * (sinTheta * sinf(phi)) + N * cosTheta;
+        si.mult = diff;
+        si.prob = diffWeight / total;
+        si.lobe = LOBE_DIFFUSE;
+    } else if (pick < diffWeight + reflWeight) {
+        f3 R = 2.0f * dot3(N, V) * N - V;
+        R = normalized3(R);
+        f3 U, Vb;
+        build_onb(R, U, Vb);
+        const float cosTheta = powf(u1, 1.0f / (alpha + 1.0f));
+        const float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
+        const float phi = 2.0f * PI_F * u2;
+        f3 H = U * (sinTheta * cosf(phi)) + Vb * (sinTheta * sinf(phi)) + R * cosTheta;
+        H = normalized3(H);
+        if (phong) dir = H;
+        else dir = normalized3(2.0f * dot3(V, H) * H - V);
+        si.mult = refl;
+        si.prob = reflWeight / total;
+        si.lobe = LOBE_SPECULAR;
+    } else {
+        const f3 I = -V;
+        float n1 = 1.0f, n2 = m.ior;
+        if (!s.front) {
+            n1 = m.ior;
+            n2 = 1.0f;
+        }
+        const float eta = n1 / n2;
+        const float cosi = -dot3(N, I);
+        const float k = 1.0f - eta * eta * (1.0f - cosi * cosi);
+        if (k < 0.0f) return false;
+        dir = eta * I + (eta * cosi - sqrtf(k)) * N;
+        dir = normalized3(dir);
+        const f3 T = dir;
+        if (alpha > 0.0f) {
+            f3 U, Vb;
+            build_onb(T, U, Vb);
+            const float cosTheta = powf(u1, 1.0f / (alpha + 1.0f));
+            const float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
+            const float phi = 2.0f * PI_F * u2;
+            dir = U * (sinTheta * cosf(phi)) + Vb * (sinTheta * sinf(phi)) + T * cosTheta;
+            dir = normalized3(dir);
+        }
+        si.mult = refr;
+        si.prob = refrWeight / total;
+        si.lobe = LOBE_TRANSMISSION;
+    }
+    return true;
+}
+
+// One Shade() (Shading_Legacy.cpp:366-514 Blinn, :517-659 Phong, :662-694 microfacet) whose result enters the sample
+// with weight w: adds w x (its own terms) to S.L and queues its TraceSecondaryRay calls.
+__device__ __forceinline__ void lg_shade(const LgScene& g, const DevMaterial& m, const SampCtx& sx, int obj, f3 w, int bounce,
+                                         int diffuseDepth, LgState& S) {
+    const DevScene& sc = g.sc;
+    const bool canBounce = bounce < LG_MAX_BOUNCES;
+    const uint32_t node = sx.stream;
+    if (m.type == RTX_MTL_MICROFACET) {
+        const f3 N = normalized3(sx.N);
+        const f3 base = eval_tc(sc, m.kd, m.kd_tex, sx.uvw);
+        f3 result = mk3(0.0f);
+        if (bounce == 0) {
+            for (int l = 0; l < sc.n_lights; ++l) {
+                const f3 Ldir = normalized3(normalized3(ld3(sc.lights[l].pos) - sx.P));   // Illuminate's dir, then Ldir.Normalize() (:672)
+                const float NdotL = fmaxf(0.0f, dot3(N, Ldir));
+                if (!(NdotL > 0.0f)) continue;   // Illuminate's result would be multiplied by nothing
+                f3 unused;
+                const f3 Li = lg_illuminate(g, sx, obj, sc.lights[l], l, unused, S);
+                result = result + base * Li * NdotL;
+            }
+        }
+        if (max3c(base) > 1e-6f && canBounce) {
+            f3 indirDir;
+            DirInfo si;
+            if (lg_generate_sample(sc, m, sx, indirDir, si)) lg_push(S, sx, indirDir, w * si.mult, mk3(0.0f), node * 3u + 1u, bounce + 1, diffuseDepth);
+        }
+        result = result + eval_tc(sc, m.ke, m.ke_tex, sx.uvw);
+        S.L = S.L + w * result;
+        return;
+    }
+    const bool phong = m.type == RTX_MTL_PHONG;
+    f3 N = normalized3(sx.N);
+    if (!sx.front) N = -N;
+    const f3 V = normalized3(sx.V);
+    const f3 I = -V;
+    const float alpha = m.gloss;
+    const f3 kd = eval_tc(sc, m.kd, m.kd_tex, sx.uvw);
+    const f3 ks = eval_tc(sc, m.ks, m.ks_tex, sx.uvw);
+
+    // direct light (USE_PHOTON_MAP_DIRECT = false)
+    f3 local = mk3(0.0f);
+    for (int l = 0; l < sc.n_lights; ++l) {
+        const DevLight& light = sc.lights[l];
+        const f3 Ldir = normalized3(normalized3(ld3(light.pos) - sx.P));   // Illuminate's dir, then Ldir.Normalize() (:408)
+        const float NdotL = fmaxf(0.0f, dot3(N, Ldir));
+        if (!(NdotL > 0.0f)) continue;   // the reference calls Illuminate first and drops its result here (:406-410)
+        f3 unused;
+        const f3 Li = lg_illuminate(g, sx, obj, light, l, unused, S);
+        if (!phong) {
+            local = local + (kd / PI_F) * Li * NdotL;
+            const f3 H = normalized3(Ldir + V);
+            const float NdotH = fmaxf(0.0f, dot3(N, H));
+            if (NdotH > 0.0f) local = local + (ks * (alpha + 2.0f) / (8.0f * PI_F)) * Li * powf(NdotH, alpha);
+        } else {
+            f3 lightContrib = (kd / PI_F) * Li * NdotL;
+            const f3 R = normalized3(2.0f * dot3(N, Ldir) * N - Ldir);
+            const float RdotV = fmaxf(0.0f, dot3(R, V));
+            if (RdotV > 0.0f) lightContrib = lightContrib + (ks * (alpha + 1.0f) / (2.0f * PI_F)) * Li * powf(RdotV, alpha);
+            local = local + lightContrib;
+        }
+    }
+
+    // reflection / refraction decide the weight of `local` (:499-507), so they come first here
+    const f3 refl = eval_tc(sc, m.kr, m.kr_tex, sx.uvw);
+    const f3 refrRaw = eval_tc(sc, m.kt, m.kt_tex, sx.uvw);
+    const bool isDielectric = max3c(refrRaw) > 1e-6f;
+    const bool spawn = (isDielectric || max3c(refl) > 1e-4f) && canBounce;
+    const f3 wLocal = (spawn && isDielectric) ? w * (mk3(1.0f) - refl) : w;
+
+    // indirect light (:419-457)
+    f3 indirect = mk3(0.0f), causticTerm = mk3(0.0f);
+    const bool hasDiffuse = max3c(kd) > 1e-6f;
+    if (hasDiffuse && g.pmCaustic.n > 0) causticTerm = (kd / PI_F) * estimate_irradiance(g.pmCaustic, sx.P, sx.N);
+    f3 diffDir = mk3(0.0f), diffW = mk3(0.0f);
+    bool pushDiffuse = false;
+    if (g.pmGlobal.n > 0 && !(diffuseDepth <= 1)) {
+        indirect = indirect + (kd / PI_F) * estimate_irradiance(g.pmGlobal, sx.P, sx.N);
+    } else if (hasDiffuse && canBounce) {
+        DirInfo si;
+        if (lg_generate_sample(sc, m, sx, diffDir, si)) {
+            diffW = wLocal * (si.mult / si.prob);
+            pushDiffuse = true;
+        }
+    }
+    indirect = indirect + causticTerm;
+    local = local + indirect;
+    S.L = S.L + wLocal * local + w * eval_tc(sc, m.ke, m.ke_tex, sx.uvw);
+
+    // calls are queued in reverse so that they are traced in the reference's order: diffuse, reflection, refraction
+    if (spawn) {
+        const float kr = isDielectric ? lg_fresnel_exact(I, N, m.ior) : 1.0f;
+        if (isDielectric) {
+            float n1 = 1.0f, n2 = m.ior;
+            const float cosi = -dot3(N, I);
+            if (!sx.front) {
+                n1 = m.ior;
+                n2 = 1.0f;
+            }
+            const float eta = n1 / n2;
+            const float k = 1.0f - eta * eta * (1.0f - cosi * cosi);
+            if (k >= 0.0f) {
+                f3 T = eta * I + (eta * cosi - sqrtf(k)) * N;
+                T = normalized3(T);
+                const f3 dir = lg_glossy_dir(sx, T, alpha, false, V);
+                lg_push(S, sx, dir, w * ((1.0f - kr) * refrRaw), ld3(m.absorption), node * 3u + 3u, bounce + 1, diffuseDepth);
+            }
+        }
+        const f3 rdir = lg_glossy_dir(sx, N, alpha, true, V);
+        lg_push(S, sx, rdir, isDielectric ? w * kr : w * refl, mk3(0.0f), node * 3u + 2u, bounce + 1, diffuseDepth);
+    }
+    if (pushDiffuse) lg_push(S, sx, diffDir, diffW, mk3(0.0f), node * 3u + 1u, bounce + 1, diffuseDepth);
+}
+
+// TraceSecondaryRay from the biased ray on (ShadeInfoAdapter.h:114-230) for every queued call
+__device__ __forceinline__ void lg_run(const LgScene& g, unsigned long long key, LgState& S) {
+    const DevScene& sc = g.sc;
+    while (S.sp > 0) {
+        const LgCall c = S.stack[--S.sp];
+        const RayT r{c.o.x, c.o.y, c.o.z, c.d.x, c.d.y, c.d.z, RTX_BIG};
+        S.rays++;
+        float bestLightT = RTX_BIG;
+        int visibleLight = -1;
+        for (int l = 0; l < sc.n_lights; ++l) {
+            const float t = lg_light_intersect(sc.lights[l], c.o, c.d);
+            if (t > 0.0f && t < bestLightT) {
+                bestLightT = t;
+                visibleLight = l;
+            }
+        }
+        uint32_t nc = 0, tc = 0;
+        const HitT h = traverse_closest<false>(sc, r, RTX_HIT_FRONT_AND_BACK, g.st, &nc, &tc);
+        const bool hitGeom = h.slot >= 0;
+        if (visibleLight >= 0 && (!hitGeom || bestLightT < h.t)) {
+            const DevLight& light = sc.lights[visibleLight];
+            const f3 rad = clamp01_3(ld3(light.intensity) / (PI_F * light.size * light.size));
+            S.L = S.L + c.w * (rad * lg_absorption_factor(c.absorb, bestLightT));
+            continue;
+        }
+        if (!hitGeom) {
+            const f3 nd = normalized3(c.d);
+            const f3 env = sc.env_tex >= 0 ? ld3(sc.env) * tex_eval_env(sc, sc.env_tex, nd) : ld3(sc.env);
+            S.L = S.L + c.w * (env * lg_absorption_factor(c.absorb, RTX_BIG));
+            continue;
+        }
+        SurfHit sh;
+        resolve_triangle(sc, r, h, sh);
+        const float hitDist = len3(sh.p - c.o);
+        const float dist = sh.front ? hitDist : 0.0f;
+        const int mi = sc.objs[sh.obj].material;
+        if (mi < 0) continue;
+        const DevMaterial& m = sc.mtls[mi];
+        apply_bump(sc, m, sh);
+        SampCtx sx;
+        sx.P = sh.p;
+        sx.V = -normalized3(c.d);
+        sx.N = sh.N;
+        sx.GN = sh.GN;
+        sx.uvw = sh.uvw;
+        sx.front = sh.front;
+        sx.key = key;
+        sx.stream = c.node;
+        const int bounce = (int)(c.bounceDepth & 0xFFu);
+        const int dd = (int)(c.bounceDepth >> 8) + (mtl_is_photon_surface(m) ? 1 : 0);
+        lg_shade(g, m, sx, sh.obj, c.w * lg_absorption_factor(c.absorb, dist), bounce, dd, S);
+    }
+}
+
+// TraceLegacy (RayCaster.cpp:579-631) for every camera sample of the pass, from the primary hits of extend_kernel.
+// Persistent grid: thread t handles queue items t, t + threads, ... (the traversal spill slab is sized for the grid).
+__global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene sc, DevCamera cam, PathPool pool, DevPhotonMap pmGlobal,
+                                                            DevPhotonMap pmCaustic, SegQ qIn, const uint32_t* __restrict__ queueIn,
+                                                            uint32_t n, unsigned long long seed, int sBase, int S,
+                                                            const int* __restrict__ pixels, uint2* spill) {
+    __shared__ uint32_t qtab[SEGQ_TABLE_WORDS];
+    __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
+    segq_load_table(qIn, qtab);
+    __syncthreads();
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, nThreads = gridDim.x * blockDim.x;
+    const LgScene g{sc, pmGlobal, pmCaustic, TravStack{&lds_stack[threadIdx.x], spill + gtid, nThreads}};
+    unsigned long long rays = 0, shadows = 0;
+    for (uint32_t i = gtid; i < n; i += nThreads) {
+        const uint32_t slot = queueIn[segq_item_index(qtab, i)];
+        const float4 ra = pool.rays[2 * (size_t)slot], rb = pool.rays[2 * (size_t)slot + 1];
+        const float4 hv = pool.hits[slot];
+        const RayT ray{ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, ra.w};
+        const HitT h{hv.x, hv.y, hv.z, __float_as_int(hv.w)};
+        const uint32_t lane64 = slot & 63u, cs = slot >> 6;
+        const int pix = pixels[(cs / (uint32_t)S) * 64u + lane64];
+        const int sIdx = sBase + (int)(cs % (uint32_t)S);
+        const f3 rdir = mk3(ray.dx, ray.dy, ray.dz), rorg = mk3(ray.ox, ray.oy, ray.oz);
+        LgState st;
+        st.L = mk3(0.0f);
+        st.sp = 0;
+        st.rays = st.shadows = 0;
+        float primaryDist = RTX_BIG;
+        if (h.slot == -1) {   // :583-593
+            const f3 nd = normalized3(rdir);
+            float uEnv = 0.0f, vEnv = 0.0f;
+            dir_to_screen_uv(cam, nd, uEnv, vEnv);
+            const bool hasBackground = has_map_or_value(sc.bg, sc.bg_tex);
+            const bool hasEnvironment = has_map_or_value(sc.env, sc.env_tex);
+            const f3 backplate = hasBackground ? eval_tc(sc, sc.bg, sc.bg_tex, mk3(uEnv, vEnv, 0.0f)) : mk3(0.0f);
+            f3 envLight = mk3(0.0f);
+            if (hasEnvironment) envLight = sc.env_tex >= 0 ? ld3(sc.env) * tex_eval_env(sc, sc.env_tex, nd) : ld3(sc.env);
+            const f3 bgEmit = (hasBackground && sc.bg_emission > 0.0f) ? backplate * sc.bg_emission : mk3(0.0f);
+            st.L = (hasBackground ? backplate : envLight) + bgEmit;
+        } else {
+            SurfHit sh;
+            if (h.slot >= 0) resolve_triangle(sc, ray, h, sh);
+            else resolve_light(sc, ray, h, sh);
+            primaryDist = len3(sh.p - rorg);
+            if (sh.light >= 0) {   // :613-624
+                const DevLight& light = sc.lights[sh.light];
+                st.L = ld3(light.intensity) / (PI_F * light.size * light.size);
+            } else {
+                const int mi = sc.objs[sh.obj].material;
+                f3 alb = mk3(0.0f);
+                if (mi >= 0) {
+                    const DevMaterial& m = sc.mtls[mi];
+                    apply_bump(sc, m, sh);
+                    SampCtx sx;
+                    sx.P = sh.p;
+                    sx.V = -normalized3(rdir);
+                    sx.N = sh.N;
+                    sx.GN = sh.GN;
+                    sx.uvw = sh.uvw;
+                    sx.front = sh.front;
+                    sx.key = rng_key(seed, (uint32_t)pix, (uint32_t)sIdx);
+                    sx.stream = 0u;
+                    lg_shade(g, m, sx, sh.obj, mk3(1.0f), 0, 0, st);
+                    lg_run(g, sx.key, st);
+                    alb = m.type == RTX_MTL_MICROFACET ? mk3(0.5f) : eval_tc(sc, m.kd, m.kd_tex, sx.uvw);   // GetDiffuseAlbedo :135-138
+                }
+                const f3 fn = safe_normalize3(sh.GN);
+                pool.albedo[slot] = make_float4(alb.x, alb.y, alb.z, 1.0f);
+                pool.normal[slot] = make_float4(fn.x, fn.y, fn.z, 1.0f);
+            }
+        }
+        pool.L[slot] = make_float4(st.L.x, st.L.y, st.L.z, primaryDist);
+        rays += st.rays;
+        shadows += st.shadows;
+    }
+    atomicAdd(&pool.rayCounters[0], shadows);
+    atomicAdd(&pool.rayCounters[1], rays);
+}
+
+void launch_legacy(const DevScene& sc, const LaunchCfg& cfg, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pmGlobal,
+                   const DevPhotonMap& pmCaustic, const SegQ& qIn, const uint32_t* queueIn, uint32_t n, unsigned long long seed,
+                   int sBase, int S, const int* pixels) {
+    if (!n) return;
+    const uint32_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
+    const uint32_t grid = need < (uint32_t)cfg.gridBlocks ? need : (uint32_t)cfg.gridBlocks;
+    hipLaunchKernelGGL(legacy_kernel, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, cam, pool, pmGlobal, pmCaustic, qIn, queueIn, n,
+                       seed, sBase, S, pixels, cfg.spill);
+}

@@ -312,7 +312,7 @@ __device__ __forceinline__ float filter1d(int type, float radius, float x) {   /
 template <bool NEAR3>
 __global__ void film_kernel(PathPool pool, rtx_film film, const int* __restrict__ pixels, uint32_t nPix, int S, int W, int H,
                             int filterType, float filterRadius, int resetZ, float4* __restrict__ samplesOut, int sBase,
-                            int sppTotal) {
+                            int sppTotal, float radianceClamp) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nPix) return;
     const int pix = pixels[i];
@@ -337,8 +337,8 @@ __global__ void film_kernel(PathPool pool, rtx_film film, const int* __restrict_
     for (int s = 0; s < S; ++s) {
         const uint32_t slot = (chunk * (uint32_t)S + (uint32_t)s) * 64u + lane;
         const float4 L4 = pool.L[slot];
-        // kRadianceClamp (RayCaster.cpp:569-571)
-        const float cr = fminf(L4.x, 10.0f), cg = fminf(L4.y, 10.0f), cb = fminf(L4.z, 10.0f);
+        // kRadianceClamp (RayCaster.cpp:569-571) in path mode; TraceLegacy returns its radiance unclamped
+        const float cr = fminf(L4.x, radianceClamp), cg = fminf(L4.y, radianceClamp), cb = fminf(L4.z, radianceClamp);
         if (samplesOut) samplesOut[(size_t)pix * sppTotal + sBase + s] = make_float4(cr, cg, cb, L4.w);
         if (L4.w < bestZ) bestZ = L4.w;
         cnt += 1;
@@ -540,15 +540,15 @@ void launch_resolve(const PathPool& pool, const SegQ& qIn, const uint32_t* queue
     hipLaunchKernelGGL(resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pool, qIn, queueIn, n, nLights, usePhotons);
 }
 void launch_film(const PathPool& pool, const rtx_film& film, const int* pixels, uint32_t nPix, int S, int W, int H, int filterType,
-                 float filterRadius, int resetZ, float4* samplesOut, int sBase, int sppTotal, hipStream_t stream) {
+                 float filterRadius, int resetZ, float4* samplesOut, int sBase, int sppTotal, float radianceClamp, hipStream_t stream) {
     if (!nPix) return;
     const bool near3 = filterType == RTX_FILTER_TENT && (filterRadius <= 0.0f || filterRadius <= 1.0f);
     if (near3)
         hipLaunchKernelGGL(film_kernel<true>, dim3((nPix + 255) / 256), dim3(256), 0, stream, pool, film, pixels, nPix, S, W, H,
-                           filterType, filterRadius, resetZ, samplesOut, sBase, sppTotal);
+                           filterType, filterRadius, resetZ, samplesOut, sBase, sppTotal, radianceClamp);
     else
         hipLaunchKernelGGL(film_kernel<false>, dim3((nPix + 255) / 256), dim3(256), 0, stream, pool, film, pixels, nPix, S, W, H,
-                           filterType, filterRadius, resetZ, samplesOut, sBase, sppTotal);
+                           filterType, filterRadius, resetZ, samplesOut, sBase, sppTotal, radianceClamp);
 }
 void launch_adaptive(const PathPool& pool, const int* pixels, uint32_t nPix, float maxHalf, int sppMax, int* pixelsNext,
                      uint32_t* counter, hipStream_t stream) {

@@ -215,6 +215,10 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     std::memset(&pm, 0, sizeof(pm));
     const bool usePhotons = photons && rp->use_photons;
     if (usePhotons) photon_device_map(photons, 1, pm);
+    const bool legacy = rp->shading_mode == RTX_SHADING_LEGACY;
+    DevPhotonMap pmGlobal;
+    std::memset(&pmGlobal, 0, sizeof(pmGlobal));
+    if (usePhotons && legacy) photon_device_map(photons, 0, pmGlobal);   // gathered in legacy mode only (Shading_Legacy.cpp:440-444)
 
     // path pool sizing: S samples per pixel per pass
     int S = rp->samples_per_pass;
@@ -290,6 +294,19 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
             launch_segq_scan(sqIn, gridGen, 256, 1, pool.totals, 2, st);
             uint32_t n = (uint32_t)(curValid * (size_t)Sp);   // = totals[2]: every valid pixel generates Sp paths
             out.paths += n;
+            if (legacy && n > 0) {
+                // primary hits by the extend kernel, then the whole recursion of every sample in one kernel
+                out.rays_primary += n;
+                tm.begin(0, st);
+                launch_extend_queue(s->dev, s->cfg, pool.rays, sqIn, qin, n, RTX_HIT_FRONT_AND_BACK, 1, pool.hits);
+                tm.end(st);
+                out.extend_launches++;
+                tm.begin(2, st);
+                launch_legacy(s->dev, s->cfg, dc, pool, pmGlobal, pm, sqIn, qin, n, rp->seed, sBase, Sp, curPixels);
+                tm.end(st);
+                RTX_HIP(hipStreamSynchronize(st));   // one pass at a time, so that rtx_cancel is seen between passes
+                n = 0;
+            }
             for (int bounce = 0; bounce < rp->max_bounces && n > 0 && !s->cancel.load(std::memory_order_relaxed); ++bounce) {
                 if (bounce == 0) out.rays_primary += n;
                 else out.rays_bounce += n;
@@ -330,7 +347,8 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
             // a pass interrupted by rtx_cancel holds unfinished paths: it is dropped, earlier passes stay
             if (!s->cancel.load(std::memory_order_relaxed))
                 launch_film(pool, *film, curPixels, nPix, Sp, W, H, rp->filter_type, rp->filter_radius,
-                            (done == 0 && (spec ? spec->resetZ != 0 : round == 1)) ? 1 : 0, samplesOut, sBase, sppMax, st);
+                            (done == 0 && (spec ? spec->resetZ != 0 : round == 1)) ? 1 : 0, samplesOut, sBase, sppMax,
+                            legacy ? 3.0e38f : 10.0f, st);
             done += Sp;
         }
         roundBase += target;

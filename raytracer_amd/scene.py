@@ -170,7 +170,7 @@ def make_camera(pos, target, up=(0, 1, 0), fov=40.0, focaldist=1.0, dof=0.0, wid
 
 def render_params(spp_min=128, spp_max=None, max_bounces=64, seed=0x9E3779B97F4A7C15, ci_halfwidth=0.005,
                   filter_type=_ffi.FILTER_TENT, filter_radius=1.0, tile_size=16, rank=0, world=1,
-                  samples_per_pass=0, index_stride=1024, use_photons=0):
+                  samples_per_pass=0, index_stride=1024, use_photons=0, shading_mode=_ffi.SHADING_PATH):
     """Defaults are the reference's compile-time constants (RayCaster.cpp:51-56,30-31,358,1152)."""
     p = _ffi.RenderParams()
     p.spp_min = spp_min
@@ -183,4 +183,5 @@ def render_params(spp_min=128, spp_max=None, max_bounces=64, seed=0x9E3779B97F4A
     p.tile_size, p.rank, p.world = tile_size, rank, world
     p.samples_per_pass = samples_per_pass
     p.use_photons = use_photons
+    p.shading_mode = shading_mode   # _ffi.SHADING_LEGACY = the reference's SHADING_USE_LEGACY=1 build
     return p

@@ -1,0 +1,109 @@
+"""Known answers for the legacy shading mode of the oracle (oracle/oracle_legacy.cpp: TraceLegacy, RayCaster.cpp:579-631
+-> Shade() of Shading_Legacy.cpp), computed independently in float64 from the formulas of the reference source.
+The reference holds no fixtures for this mode: these analytic cases pin the restatement.
+"""
+import numpy as np
+import pytest
+
+from raytracer_amd import _ffi
+from raytracer_amd.scene import Light, Material, Mesh, SceneData, make_camera, render_params
+from tests.oracle_ffi import OracleScene
+
+
+def quad_scene(mtl, y=0.0, half=50.0):
+    sd = SceneData()
+    sd.materials = [mtl]
+    v = np.array([[-half, y, -half], [half, y, -half], [half, y, half], [-half, y, half]], np.float32)
+    sd.meshes = [Mesh(v, [[0, 2, 1], [0, 3, 2]], vn=np.tile([[0, 1, 0]], (4, 1)), material=0)]
+    return sd
+
+
+def legacy(spp=1):
+    return render_params(spp_min=spp, shading_mode=_ffi.SHADING_LEGACY)
+
+
+def test_lambert_point_light_plus_environment_bounce():
+    """MtlBlinn::Shade on a pure diffuse plane: local = kd/pi * I/d^2 * N.L (Shading_Legacy.cpp:127,132,411); the one
+    diffuse bounce (cosine lobe, mult = kd, prob = 1: :729-730, :451) sees the constant environment E
+    (ShadeInfoAdapter.h:228): + kd * E. Nothing is clamped."""
+    kd, I, E = 0.6, 40.0, 0.25
+    sd = quad_scene(Material(diffuse=(kd, kd, kd), specular=(0, 0, 0), glossiness=10.0))
+    sd.lights = [Light((0, 2, 0), (I, I, I), size=0.0, attenuation=1.0)]
+    sd.environment = (E, E, E)
+    cam = make_camera((0, 3, 0.001), (0, 0, 0), (0, 0, -1), fov=20, width=8, height=8)
+    s = OracleScene(sd).render_samples(cam, legacy(4))
+    expect = kd / np.pi * I / 4.0 + kd * E
+    assert s[4, 4, :, 0] == pytest.approx(expect, rel=2e-2)
+    assert expect > 1.0 and s[4, 4, 0, 3] == pytest.approx(3.0, rel=1e-2)
+
+
+def test_shadow_ray_bias_rules():
+    """TraceShadowRay (ShadeInfoAdapter.h:49-88): a sheet between the receiver and the light blocks it; the same
+    sheet beyond the light does not (finite segment, :82-84)."""
+    kd, I = 0.5, 10.0
+    for sheet_y, lit in ((1.0, False), (3.0, True)):
+        sd = quad_scene(Material(diffuse=(kd, kd, kd), specular=(0, 0, 0)))
+        v = np.array([[-1, sheet_y, -1], [1, sheet_y, -1], [1, sheet_y, 1], [-1, sheet_y, 1]], np.float32)
+        sd.materials.append(Material(diffuse=(0, 0, 0), specular=(0, 0, 0)))
+        sd.meshes.append(Mesh(v, [[0, 1, 2], [0, 2, 3]], material=1))
+        sd.lights = [Light((0, 2, 0), (I, I, I), size=0.0)]
+        cam = make_camera((6, 1.5, 0), (0, 0, 0), (0, 1, 0), fov=4, width=8, height=8)   # looks under / past the sheet
+        s = OracleScene(sd).render_samples(cam, legacy())
+        centre = s[4, 4, 0, 0]
+        if lit:
+            P = np.array([6, 1.5, 0.0]) + (np.array([0, 0, 0.0]) - np.array([6, 1.5, 0.0])) * 1.0
+            assert centre == pytest.approx(kd / np.pi * I / 4.0, rel=5e-2)
+        else:
+            assert centre == 0.0
+
+
+def test_mirror_and_glass_weights():
+    """Reflection / refraction weights of MtlBlinn::Shade (:459-507). Perfect mirror (kr = 1, kd = 0): result =
+    reflectionColor * refl = E. Glass sheet hit head-on (kt = 1, ior 1.5): kr = FresnelExact = 0.04;
+    result = E * kr + refraction * (1 - kr), and the refraction ray's own Shade() at the back face returns
+    E * kr' + E * (1 - kr') = E with nothing absorbed -> E overall."""
+    E = 0.5
+    for mtl in (Material(diffuse=(0, 0, 0), specular=(0, 0, 0), reflection=(1, 1, 1), glossiness=1e6),
+                Material(diffuse=(0, 0, 0), specular=(0, 0, 0), refraction=(1, 1, 1), ior=1.5, glossiness=1e6)):
+        sd = quad_scene(mtl)
+        sd.environment = (E, E, E)
+        cam = make_camera((0, 3, 0.001), (0, 0, 0), (0, 0, -1), fov=10, width=8, height=8)
+        s = OracleScene(sd).render_samples(cam, legacy(2))
+        assert s[4, 4, :, 0] == pytest.approx(E, rel=1e-3)
+
+
+def test_absorption_and_depth_limit():
+    """A refraction ray that misses everything has dist = BIGFLOAT (ShadeInfoAdapter.h:95): Beer-Lambert then removes
+    the absorbed channels entirely (:359, :325-328) while unabsorbed ones pass; CanBounce stops the recursion at
+    5 levels (:44): two facing mirrors return black, not an endless chain."""
+    E = 0.5
+    sd = quad_scene(Material(diffuse=(0, 0, 0), specular=(0, 0, 0), refraction=(1, 1, 1), ior=1.0, glossiness=1e6,
+                             absorption=(2.0, 0.0, 0.0)))
+    sd.environment = (E, E, E)
+    cam = make_camera((0, 3, 0.001), (0, 0, 0), (0, 0, -1), fov=10, width=8, height=8)
+    s = OracleScene(sd).render_samples(cam, legacy())
+    # ior 1: kr = 0, the refracted ray leaves through nothing -> environment, red absorbed over "infinite" distance
+    assert s[4, 4, 0, 0] == pytest.approx(0.0, abs=1e-6) and s[4, 4, 0, 1] == pytest.approx(E, rel=1e-3)
+
+    mirror = Material(diffuse=(0, 0, 0), specular=(0, 0, 0), reflection=(1, 1, 1), glossiness=1e6)
+    sd = quad_scene(mirror, y=0.0)
+    v = sd.meshes[0].v + np.array([0, 6, 0], np.float32)
+    sd.meshes.append(Mesh(v, [[0, 1, 2], [0, 2, 3]], material=0))
+    sd.environment = (E, E, E)
+    cam = make_camera((0, 3, 0), (0.3, 0, 0), (0, 0, -1), fov=5, width=4, height=4)
+    s = OracleScene(sd).render_samples(cam, legacy())
+    assert np.all(s[..., :3] == 0.0)
+
+
+def test_sphere_light_seen_by_secondary_ray_is_clamped():
+    """A renderable light hit by a reflection ray returns Radiance clamped to [0,1] (ShadeInfoAdapter.h:173-182); seen
+    directly by the camera it is not clamped (RayCaster.cpp:613-623)."""
+    I, r = 50.0, 0.5
+    sd = quad_scene(Material(diffuse=(0, 0, 0), specular=(0, 0, 0), reflection=(1, 1, 1), glossiness=1e6))
+    sd.lights = [Light((0, 3, 0), (I, I, I), size=r)]
+    cam = make_camera((0.0, 1.0, 0.001), (0, 0, 0), (0, 0, -1), fov=4, width=4, height=4)   # mirror shows the light above
+    s = OracleScene(sd).render_samples(cam, legacy())
+    assert s[2, 2, 0, 0] == pytest.approx(1.0)
+    cam = make_camera((0.0, 1.0, 0.001), (0, 3, 0), (0, 0, -1), fov=4, width=4, height=4)   # looking at the light itself
+    s = OracleScene(sd).render_samples(cam, legacy())
+    assert s[2, 2, 0, 0] == pytest.approx(I / (np.pi * r * r), rel=1e-5)
