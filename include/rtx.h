@@ -272,6 +272,26 @@ int rtx_trace_visibility(rtx_scene* scene, const rtx_ray* rays, const float* nor
 int rtx_render_primary(rtx_scene* scene, const rtx_camera* cam, int hit_side, int* prim, float* t,
                        unsigned char* front);
 
+/* The ShadeInfo state that ShadeInfoAdapter's ray queries read (ShadeInfoAdapter.h:40-47, :60, :75, :105):
+ * hit point, shading normal, receiver node, recursion depths, and the pixel-sample key of its random numbers. */
+typedef struct {
+    float P[3], N[3];
+    int obj;                       /* GetNode(): index of the receiver's (Node,Object) pair, -1 = none          */
+    int bounce;                    /* ShadeInfo::bounce (CanBounce: bounce < 5)                                  */
+    int diffuse_depth;             /* ShadeInfoAdapter::diffuseDepth                                             */
+    int pixel, sample;             /* SetPixel (y*W+x) / SetPixelSample: key of the counter RNG                  */
+    unsigned int node;             /* this Shade() in the recursion tree: 0 = primary hit, child k of node m =
+                                    * 3m+k (k = 1 diffuse, 2 reflection, 3 refraction); keys the RNG stream      */
+} rtx_shade_point;
+
+/* Replaces: ShadeInfoAdapter::TraceSecondaryRay(Ray(P, dirs[i]), dist, recursive, isReflection)
+ * (ShadeInfoAdapter.h:94-231; legacy shading mode) for n directions from one shading point: biased origin,
+ * nearest of renderable lights and geometry, Shade() of the hit (Shading_Legacy.cpp) with its own shadow and
+ * secondary rays. `child` (1..3) names which call of the caller's Shade() this is (RNG node of the hit);
+ * photons may be NULL. color_dist[4i..4i+3] = {r, g, b, dist}. Host arrays. */
+int rtx_trace_secondary(rtx_scene* scene, const rtx_photons* photons, const rtx_shade_point* at, const float* dirs, size_t n,
+                        int recursive, int child, uint64_t seed, float* color_dist);
+
 /* Film helpers (device memory). */
 int rtx_film_clear(const rtx_film* film, int width, int height, void* stream);
 

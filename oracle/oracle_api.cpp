@@ -181,6 +181,19 @@ int orc_trace_samples(void* s, const rtx_camera* cam, const rtx_render_params* r
     return 0;
 }
 
+// ShadeInfoAdapter::TraceSecondaryRay for n directions from one shading point: out[i] = {r,g,b,dist}
+int orc_trace_secondary(void* s, void* photons, const rtx_shade_point* at, const float* dirs, size_t n, int recursive, int child,
+                        uint64_t seed, float* out) {
+    Scene* sc = (Scene*)s;
+    for (size_t i = 0; i < n; ++i) {
+        float dist = BIGFLOAT;
+        V3 col = legacy_secondary(*sc, (PhotonMapper*)photons, *at, V3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), recursive != 0, child,
+                                  seed, dist);
+        out[4 * i] = col.x; out[4 * i + 1] = col.y; out[4 * i + 2] = col.z; out[4 * i + 3] = dist;
+    }
+    return 0;
+}
+
 // CastRays. Outputs (any may be NULL): accum[W*H*4], count, z, albedo[W*H*4], normal[W*H*4] raw film;
 // linear[W*H*3], rgb8[W*H*3] resolved. counters[3] = primary, bounce, shadow-hop rays. Returns wall seconds in *secs.
 int orc_render(void* s, const rtx_camera* cam, const rtx_render_params* rp, void* photons, int nthreads, int subset_stride,

@@ -194,7 +194,7 @@ static V3 eval_environment(const Scene& scene, V3 nd) {
 // ShadeInfoAdapter.h:94-231; `child` = 1 diffuse, 2 reflection, 3 refraction (RNG node of the Shade() it leads to).
 // The isReflection flag selects between two branches (:115-183) with the same outcome: the nearest renderable light
 // in front of the geometry hit wins, its radiance clamped to [0,1].
-static V3 trace_secondary_ray(const LegacyCtx& c, const LegacyInfo& li, V3 dir, float& dist, int child) {
+static V3 trace_secondary_ray(const LegacyCtx& c, const LegacyInfo& li, V3 dir, float& dist, int child, bool recursive = true) {
     dist = BIGFLOAT;
     if (!(li.bounce < kMaxSpecularBounces)) return V3(0, 0, 0);
     const float baseBias = 1e-4f;
@@ -244,7 +244,7 @@ static V3 trace_secondary_ray(const LegacyCtx& c, const LegacyInfo& li, V3 dir, 
         s2.s.set_hit(ray, h);
         s2.obj = h.obj;
         s2.diffuseDepth = li.diffuseDepth + (mtl_is_photon_surface(*mtl) ? 1 : 0);
-        s2.bounce = li.bounce + 1;   // recursive = true on every call path of Shading_Legacy.cpp
+        s2.bounce = recursive ? li.bounce + 1 : kMaxSpecularBounces;   // :217-223; Shading_Legacy.cpp always recurses
         s2.node = li.node * 3u + (uint32_t)child;
         s2.s.stream = s2.node;
         return shade(c, *mtl, s2);
@@ -478,6 +478,25 @@ static V3 shade(const LegacyCtx& c, const Material& m, const LegacyInfo& li) {
     }
     result = result + sc.eval_tc(m.d.emission, m.d.emission_tex, s.uvw);
     return result;
+}
+
+// ShadeInfoAdapter::TraceSecondaryRay called from outside Shade() (the boundary entry point of SURVEY.md §8b)
+V3 legacy_secondary(const Scene& scene, const PhotonMapper* mapper, const rtx_shade_point& at, V3 dir, bool recursive, int child,
+                    uint64_t seed, float& dist) {
+    Camera cam{};
+    LegacyCtx c{scene, cam, mapper, nullptr, seed, (uint32_t)at.pixel, (uint32_t)at.sample};
+    LegacyInfo li;
+    li.s.seed = seed;
+    li.s.ka = (uint32_t)at.pixel;
+    li.s.kb = (uint32_t)at.sample;
+    li.s.stream = at.node;
+    li.s.P = V3(at.P[0], at.P[1], at.P[2]);
+    li.s.N = V3(at.N[0], at.N[1], at.N[2]);
+    li.obj = at.obj;
+    li.bounce = at.bounce;
+    li.diffuseDepth = at.diffuse_depth;
+    li.node = at.node;
+    return trace_secondary_ray(c, li, dir, dist, child, recursive);
 }
 
 // RayCaster.cpp:579-631

@@ -327,10 +327,11 @@ bool Scene::intersect_node(const Ray& inRay, Hit& outHit, int hitSide, bool useB
                     }
                 }
                 if (hitChild && !m.identity) {
-                    // :93 node->FromNodeCoords: p = tm*p+pos, normals by itm^T (framework convention)
+                    // :93 node->FromNodeCoords: p = tm*p+pos, normals by itm^T and renormalised (framework convention;
+                    // the legacy mode's bias rules read N unnormalised, ShadeInfoAdapter.h:60-67)
                     childLocal.p = xf_point(m.tm, childLocal.p);
-                    childLocal.N = xf_vec_t(m.itm, childLocal.N);
-                    childLocal.GN = xf_vec_t(m.itm, childLocal.GN);
+                    childLocal.N = normalized(xf_vec_t(m.itm, childLocal.N));
+                    childLocal.GN = normalized(xf_vec_t(m.itm, childLocal.GN));
                     childLocal.dpdu = xf_vec(m.tm, childLocal.dpdu);
                     childLocal.dpdv = xf_vec(m.tm, childLocal.dpdv);
                 }

@@ -120,6 +120,8 @@ bool mtl_is_photon_surface(const Material& m);
 // legacy shading mode (oracle_legacy.cpp): TraceLegacy, RayCaster.cpp:579-631
 PathResult trace_legacy(const Scene& sc, const Camera& cam, Ray ray, int px, int py, int sampleIdx, const PhotonMapper* mapper,
                         uint64_t seed, PathCounters* pc);
+V3 legacy_secondary(const Scene& sc, const PhotonMapper* mapper, const rtx_shade_point& at, V3 dir, bool recursive, int child,
+                    uint64_t seed, float& dist);
 PathResult trace_radiance(const Scene& sc, const Camera& cam, Ray ray, int px, int py, int sampleIdx, const PhotonMapper* mapper,
                           const rtx_render_params& rp, PathCounters* pc);
 

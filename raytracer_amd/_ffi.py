@@ -82,6 +82,11 @@ class RenderParams(C.Structure):
                 ("samples_per_pass", C.c_int), ("use_photons", C.c_int), ("shading_mode", C.c_int)]
 
 
+class ShadePoint(C.Structure):
+    _fields_ = [("P", C.c_float * 3), ("N", C.c_float * 3), ("obj", C.c_int), ("bounce", C.c_int), ("diffuse_depth", C.c_int),
+                ("pixel", C.c_int), ("sample", C.c_int), ("node", C.c_uint)]
+
+
 class Film(C.Structure):
     _fields_ = [("accum", C.c_void_p), ("count", C.c_void_p), ("z", C.c_void_p), ("albedo", C.c_void_p),
                 ("normal", C.c_void_p)]
@@ -137,6 +142,7 @@ SYMBOLS = [
     ("rtx_trace_closest", C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_int, _vp]),
     ("rtx_trace_closest_device", C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_int, _vp, _vp]),
     ("rtx_trace_visibility", C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp]),
+    ("rtx_trace_secondary", C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_uint64, _vp]),
     ("rtx_render_primary", C.c_int, [_vp, C.POINTER(Camera), C.c_int, _vp, _vp, _vp]),
     ("rtx_film_clear", C.c_int, [C.POINTER(Film), C.c_int, C.c_int, _vp]),
     ("rtx_render_accumulate", C.c_int, [_vp, C.POINTER(Camera), C.POINTER(RenderParams), _vp, C.POINTER(Film),

@@ -76,6 +76,15 @@ class Scene:
                                                        int(use_transmittance), vis.ctypes.data))
         return vis
 
+    def trace_secondary(self, at, dirs, recursive=True, child=2, seed=0x9E3779B97F4A7C15, photons=None):
+        """ShadeInfoAdapter::TraceSecondaryRay (legacy mode) for directions `dirs` from the shading point `at`
+        (_ffi.ShadePoint): (n, 4) array of {r, g, b, dist}."""
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros((dirs.shape[0], 4), dtype=np.float32)
+        _check(self.lib, self.lib.rtx_trace_secondary(self.h, photons.h if photons else None, C.byref(at), dirs.ctypes.data,
+                                                      dirs.shape[0], int(recursive), child, seed, out.ctypes.data))
+        return out
+
     def render_primary(self, cam, hit_side=_ffi.HIT_FRONT):
         n = cam.width * cam.height
         prim = np.zeros(n, dtype=np.int32)

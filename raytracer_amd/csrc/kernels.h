@@ -73,6 +73,9 @@ void launch_film(const PathPool& pool, const rtx_film& film, const int* pixels, 
 void launch_legacy(const DevScene& sc, const LaunchCfg& cfg, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pmGlobal,
                    const DevPhotonMap& pmCaustic, const SegQ& qIn, const uint32_t* queueIn, uint32_t n, unsigned long long seed,
                    int sBase, int S, const int* pixels);
+void launch_legacy_secondary(const DevScene& sc, const LaunchCfg& cfg, const DevPhotonMap& pmGlobal, const DevPhotonMap& pmCaustic,
+                             const rtx_shade_point& at, const float* dirs, uint32_t n, int recursive, int child, unsigned long long seed,
+                             float4* out);
 void launch_adaptive(const PathPool& pool, const int* pixels, uint32_t nPix, float maxHalf, int sppMax, int* pixelsNext,
                      uint32_t* counter, hipStream_t stream);
 void launch_fill_int(int* p, uint32_t n, int v, hipStream_t stream);

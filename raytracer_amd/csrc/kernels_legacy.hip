@@ -389,11 +389,15 @@ __device__ __forceinline__ void lg_shade(const LgScene& g, const DevMaterial& m,
     if (pushDiffuse) lg_push(S, sx, diffDir, diffW, mk3(0.0f), node * 3u + 1u, bounce + 1, diffuseDepth);
 }
 
-// TraceSecondaryRay from the biased ray on (ShadeInfoAdapter.h:114-230) for every queued call
-__device__ __forceinline__ void lg_run(const LgScene& g, unsigned long long key, LgState& S) {
+// TraceSecondaryRay from the biased ray on (ShadeInfoAdapter.h:114-230) for every queued call; firstDist receives the
+// `dist` result of the first call traced (the one a caller of rtx_trace_secondary asked for)
+__device__ __forceinline__ void lg_run(const LgScene& g, unsigned long long key, LgState& S, float* firstDist = nullptr) {
     const DevScene& sc = g.sc;
+    bool first = true;
     while (S.sp > 0) {
         const LgCall c = S.stack[--S.sp];
+        const bool isFirst = first;
+        first = false;
         const RayT r{c.o.x, c.o.y, c.o.z, c.d.x, c.d.y, c.d.z, RTX_BIG};
         S.rays++;
         float bestLightT = RTX_BIG;
@@ -412,6 +416,7 @@ __device__ __forceinline__ void lg_run(const LgScene& g, unsigned long long key,
             const DevLight& light = sc.lights[visibleLight];
             const f3 rad = clamp01_3(ld3(light.intensity) / (PI_F * light.size * light.size));
             S.L = S.L + c.w * (rad * lg_absorption_factor(c.absorb, bestLightT));
+            if (isFirst && firstDist) *firstDist = bestLightT;
             continue;
         }
         if (!hitGeom) {
@@ -424,6 +429,7 @@ __device__ __forceinline__ void lg_run(const LgScene& g, unsigned long long key,
         resolve_triangle(sc, r, h, sh);
         const float hitDist = len3(sh.p - c.o);
         const float dist = sh.front ? hitDist : 0.0f;
+        if (isFirst && firstDist) *firstDist = dist;
         const int mi = sc.objs[sh.obj].material;
         if (mi < 0) continue;
         const DevMaterial& m = sc.mtls[mi];
@@ -520,6 +526,48 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene sc, DevCame
     }
     atomicAdd(&pool.rayCounters[0], shadows);
     atomicAdd(&pool.rayCounters[1], rays);
+}
+
+// ShadeInfoAdapter::TraceSecondaryRay (ShadeInfoAdapter.h:94-231) for n directions from one shading point: the entry
+// point behind rtx_trace_secondary. out[i] = {colour, dist}.
+__global__ __launch_bounds__(TRAV_BLOCK) void legacy_secondary_kernel(DevScene sc, DevPhotonMap pmGlobal, DevPhotonMap pmCaustic,
+                                                                      rtx_shade_point at, const float* __restrict__ dirs, uint32_t n,
+                                                                      int recursive, int child, unsigned long long seed,
+                                                                      float4* __restrict__ out, uint2* spill) {
+    __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, nThreads = gridDim.x * blockDim.x;
+    const LgScene g{sc, pmGlobal, pmCaustic, TravStack{&lds_stack[threadIdx.x], spill + gtid, nThreads}};
+    for (uint32_t i = gtid; i < n; i += nThreads) {
+        LgState st;
+        st.L = mk3(0.0f);
+        st.sp = 0;
+        st.rays = st.shadows = 0;
+        float dist = RTX_BIG;
+        if (at.bounce < LG_MAX_BOUNCES) {   // CanBounce (:97)
+            SampCtx sx;
+            sx.P = ld3(at.P);
+            sx.N = ld3(at.N);
+            sx.V = sx.GN = sx.uvw = mk3(0.0f);
+            sx.front = true;
+            sx.key = rng_key(seed, (uint32_t)at.pixel, (uint32_t)at.sample);
+            sx.stream = at.node;
+            // recursive == false: the Shade() reached behaves as at the depth limit (:220-223)
+            lg_push(st, sx, mk3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), mk3(1.0f), mk3(0.0f), at.node * 3u + (uint32_t)child,
+                    recursive ? at.bounce + 1 : LG_MAX_BOUNCES, at.diffuse_depth);
+            lg_run(g, sx.key, st, &dist);
+        }
+        out[i] = make_float4(st.L.x, st.L.y, st.L.z, dist);
+    }
+}
+
+void launch_legacy_secondary(const DevScene& sc, const LaunchCfg& cfg, const DevPhotonMap& pmGlobal, const DevPhotonMap& pmCaustic,
+                             const rtx_shade_point& at, const float* dirs, uint32_t n, int recursive, int child, unsigned long long seed,
+                             float4* out) {
+    if (!n) return;
+    const uint32_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
+    const uint32_t grid = need < (uint32_t)cfg.gridBlocks ? need : (uint32_t)cfg.gridBlocks;
+    hipLaunchKernelGGL(legacy_secondary_kernel, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, pmGlobal, pmCaustic, at, dirs, n,
+                       recursive, child, seed, out, cfg.spill);
 }
 
 void launch_legacy(const DevScene& sc, const LaunchCfg& cfg, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pmGlobal,

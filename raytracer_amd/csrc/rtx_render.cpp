@@ -436,6 +436,32 @@ int64_t rtx_refine_list(const rtx_pixel_stats* st, int width, int height, float 
     return (int64_t)cnt;
 }
 
+int rtx_trace_secondary(rtx_scene* s, const rtx_photons* photons, const rtx_shade_point* at, const float* dirs, size_t n, int recursive,
+                        int child, uint64_t seed, float* color_dist) {
+    if (!s) return rtx_fail(RTX_ERR_INVALID, "scene is NULL");
+    if (n == 0) return RTX_OK;
+    if (!at || !dirs || !color_dist) return rtx_fail(RTX_ERR_INVALID, "NULL argument");
+    if (child < 1 || child > 3) return rtx_fail(RTX_ERR_INVALID, "child must be 1 (diffuse), 2 (reflection) or 3 (refraction)");
+    if (at->bounce < 0 || at->diffuse_depth < 0 || at->diffuse_depth > 255) return rtx_fail(RTX_ERR_INVALID, "bad recursion depth");
+    if (n > 0x7FFFFFFFull) return rtx_fail(RTX_ERR_TOO_LARGE, "more than 2^31 rays in one call");
+    DevPhotonMap pmGlobal, pmCaustic;
+    std::memset(&pmGlobal, 0, sizeof(pmGlobal));
+    std::memset(&pmCaustic, 0, sizeof(pmCaustic));
+    if (photons) {
+        photon_device_map(photons, 0, pmGlobal);
+        photon_device_map(photons, 1, pmCaustic);
+    }
+    int rc;
+    if ((rc = s->aux.ensure(n * 3 * sizeof(float))) != RTX_OK) return rc;
+    if ((rc = s->hits.ensure(n * sizeof(float4))) != RTX_OK) return rc;
+    RTX_HIP(hipMemcpy(s->aux.p, dirs, n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    launch_legacy_secondary(s->dev, s->cfg, pmGlobal, pmCaustic, *at, (const float*)s->aux.p, (uint32_t)n, recursive, child, seed,
+                            (float4*)s->hits.p);
+    RTX_HIP(hipGetLastError());
+    RTX_HIP(hipMemcpy(color_dist, s->hits.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
 int rtx_film_clear(const rtx_film* film, int width, int height, void* stream) {
     if (!film || !film->accum || !film->count || !film->z || width <= 0 || height <= 0) return rtx_fail(RTX_ERR_INVALID, "bad film");
     if (rtx_device_count() <= 0) return rtx_fail(RTX_ERR_NO_DEVICE, "no HIP device present");

@@ -73,7 +73,7 @@ __device__ __forceinline__ f3 eval_tc(const DevScene& sc, const float* value, in
 
 // HitInfo of a Sphere / Plane hit (objects.cpp:47-85, :100-125) followed by Node::FromNodeCoords
 // (IntersectNodeAdapter.h:93; framework convention as in the oracle: p by the node transform, normals by the
-// transposed inverse without renormalising, dpdu/dpdv as vectors).
+// transposed inverse and renormalised, dpdu/dpdv as vectors).
 __device__ __forceinline__ void resolve_analytic(const DevScene& sc, uint32_t kind, uint32_t obj, const RayT& r, const HitT& h,
                                                  SurfHit& s) {
     float p[3], d[3];
@@ -101,8 +101,8 @@ __device__ __forceinline__ void resolve_analytic(const DevScene& sc, uint32_t ki
     const float* F = X.fwd;
     const float* I = X.inv;
     s.p = xf_point3(F, hp);
-    s.GN = mk3(I[0] * GN.x + I[4] * GN.y + I[8] * GN.z, I[1] * GN.x + I[5] * GN.y + I[9] * GN.z,
-               I[2] * GN.x + I[6] * GN.y + I[10] * GN.z);
+    s.GN = normalized3(mk3(I[0] * GN.x + I[4] * GN.y + I[8] * GN.z, I[1] * GN.x + I[5] * GN.y + I[9] * GN.z,
+                           I[2] * GN.x + I[6] * GN.y + I[10] * GN.z));
     s.N = s.GN;
     s.dpdu = xf_vec3(F, dpdu);
     s.dpdv = xf_vec3(F, dpdv);

@@ -30,6 +30,7 @@ struct SamplingConfig {
     int rank = 0, world = 1;          // tile sharding across GPUs (one process per GPU)
     int samplesPerPass = 0;           // samples per pixel in flight at once; 0 = sized from free HBM
     int progressiveSamplesPerPass = 1;   // kProgressiveSamplesPerPass, RayCaster.cpp:62
+    bool legacyShading = false;       // SHADING_USE_LEGACY (ShadingConfig.h:7-13): TraceLegacy instead of TracePath
 };
 
 class RayCaster {
@@ -65,6 +66,7 @@ public:
         rp.rank = sampling.rank;
         rp.world = sampling.world;
         rp.samples_per_pass = sampling.samplesPerPass;
+        rp.shading_mode = sampling.legacyShading ? RTX_SHADING_LEGACY : RTX_SHADING_PATH;
         rtx_photons* ph = photonMapper ? photonMapper->Handle() : nullptr;
         rp.use_photons = ph ? 1 : 0;
         active = gs.Handle();

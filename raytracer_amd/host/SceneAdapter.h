@@ -46,6 +46,11 @@ public:
     rtx_scene* Handle() const { return handle; }
     // (Node, Object) pair of flattened object index i, in CollectSceneNodeObjects order (TriObj, Sphere, Plane)
     const Node* NodeOf(int obj) const { return obj >= 0 && obj < (int)nodes.size() ? nodes[obj] : nullptr; }
+    int IndexOf(const Node* n) const {
+        for (size_t i = 0; i < nodes.size(); ++i)
+            if (nodes[i] == n) return (int)i;
+        return -1;
+    }
     const std::vector<Light*>& Lights() const { return lights; }
 
 private:

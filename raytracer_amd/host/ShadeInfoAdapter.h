@@ -1,10 +1,12 @@
-// Mirror of the shadow query of the reference's RayTracer/ShadeInfoAdapter.h (legacy shading mode,
-// SHADING_USE_LEGACY=1): TraceShadowRay with its bias rules (:49-92), evaluated with one closest-hit on the GPU.
-// TraceSecondaryRay (:94-231) recurses into the legacy Shade() functions of Shading_Legacy.cpp, which are outside
-// this round's scope; it is declared and reports "not available".
+// Mirror of the ray queries of the reference's RayTracer/ShadeInfoAdapter.h (legacy shading mode,
+// SHADING_USE_LEGACY=1): TraceShadowRay with its bias rules (:49-92), evaluated with one closest-hit on the GPU, and
+// TraceSecondaryRay (:94-231), which recurses into the legacy Shade() functions of Shading_Legacy.cpp on the GPU
+// (rtx_trace_secondary). Whole frames in this mode go through RayCaster with sampling.legacyShading = true.
 #pragma once
 #include <cmath>
+#include <iostream>
 #include "IntersectNodeAdapter.h"
+#include "PhotonMapBuilder.h"
 
 namespace rtamd {
 
@@ -51,10 +53,50 @@ public:
     // ShadeInfoAdapter.h:90-92
     float TraceShadowRay(Vec3f const& dir, float t_max = BIGFLOAT) const { return TraceShadowRay(Ray(P(), dir), t_max); }
 
-    // ShadeInfoAdapter.h:94-231 — legacy recursion, not part of this round (see header comment)
-    Color TraceSecondaryRay(Ray const&, float& dist, bool = true, bool = true) const {
+    // ShadeInfo state read by the secondary rays
+    void SetPixel(int x, int y) { px = x; py = y; }
+    void SetPixelSample(int s) { sampleIdx = s; }
+    int X() const { return px; }
+    int Y() const { return py; }
+    int  GetDiffuseDepth() const { return diffuseDepth; }
+    void SetDiffuseDepth(int d) { diffuseDepth = d; }
+    bool CanBounce() const { return bounce < kMaxSpecularBounces; }   // :44
+    void SetPhotonMapper(const PhotonMapBuilder* m) { mapper = m; }   // SetPhotonMap / SetCausticsMap + radii (:26-38)
+    int bounce = 0;
+    uint64_t seed = 0x9e3779b97f4a7c15ULL;   // key of the counter RNG (deviation 1)
+    unsigned rngNode = 0;                    // this Shade() in the recursion tree (include/rtx.h, rtx_shade_point::node)
+    int imageWidth = 0;                      // for the pixel index y*W+x of the RNG key
+
+    // ShadeInfoAdapter.h:94-231. inRay.p is not read by the reference either (the ray starts at the biased P(), :111).
+    // Both values of isReflection lead to the same result (:115-183); it selects the RNG node of the hit:
+    // reflection = child 2, otherwise child 1.
+    Color TraceSecondaryRay(Ray const& inRay, float& dist, bool recursive = true, bool isReflection = true) const {
         dist = BIGFLOAT;
-        return Color(0, 0, 0);
+        if (!scene) return Color(0, 0, 0);
+        if (!CanBounce()) return Color(0, 0, 0);
+        GpuScene& gs = GetGpuScene(scene);
+        rtx_shade_point at{};
+        at.P[0] = hit.p.x; at.P[1] = hit.p.y; at.P[2] = hit.p.z;
+        at.N[0] = hit.N.x; at.N[1] = hit.N.y; at.N[2] = hit.N.z;
+        at.obj = gs.IndexOf(hit.node);
+        at.bounce = bounce;
+        at.diffuse_depth = diffuseDepth;
+        at.pixel = py * imageWidth + px;
+        at.sample = sampleIdx;
+        at.node = rngNode;
+        const float d[3] = {inRay.dir.x, inRay.dir.y, inRay.dir.z};
+        float out[4] = {0, 0, 0, BIGFLOAT};
+        if (rtx_trace_secondary(gs.Handle(), mapper ? mapper->Handle() : nullptr, &at, d, 1, recursive ? 1 : 0, isReflection ? 2 : 1,
+                                seed, out) != RTX_OK) {
+            std::cerr << "TraceSecondaryRay failed: " << rtx_last_error() << "\n";
+            return Color(0, 0, 0);
+        }
+        dist = out[3];
+        return Color(out[0], out[1], out[2]);
+    }
+    // ShadeInfoAdapter.h:233-235
+    Color TraceSecondaryRay(Vec3f const& dir, float& dist, bool isReflection = true) const {
+        return TraceSecondaryRay(Ray(P(), dir), dist, true, isReflection);
     }
 
 private:
@@ -73,6 +115,9 @@ private:
     const Scene* scene;
     HitInfo hit;
     Vec3f view;
+    const PhotonMapBuilder* mapper = nullptr;
+    int px = 0, py = 0, sampleIdx = 0, diffuseDepth = 0;
+    static constexpr int kMaxSpecularBounces = 5;   // :245
 };
 
 }  // namespace rtamd

@@ -21,6 +21,8 @@ int orc_trace_closest(void* s, const rtx_ray* rays, size_t n, int hit_side, int 
 int orc_render(void* s, const rtx_camera* cam, const rtx_render_params* rp, void* photons, int nthreads, int subset_stride, float* accum,
                int* count, float* z, float* albedo, float* normal, float* linear, unsigned char* rgb8, uint64_t* counters, double* secs);
 int orc_median_denoise(const float* in, int W, int H, int srgb, float* linear, unsigned char* rgb8);
+int orc_trace_secondary(void* s, void* photons, const rtx_shade_point* at, const float* dirs, size_t n, int recursive, int child,
+                        uint64_t seed, float* out);
 }
 
 static int failures = 0;
@@ -267,6 +269,75 @@ int main() {
     mean /= 3 * np;
     CHECK(rmse <= 0.02 * mean && zbad <= (int)np / 1000, "CastRays: rmse %.5f mean %.5f zbad %d", rmse, mean, zbad);
     CHECK(img.GetNumRenderedPixels() == (int)np, "rendered pixel counter");
+
+    // legacy shading mode (SHADING_USE_LEGACY=1): the same frame through TraceLegacy, and ShadeInfoAdapter's secondary ray
+    {
+        RayCaster rl(&scene, &cam);
+        rl.sampling.minSamples = rl.sampling.maxSamples = 4;
+        rl.sampling.legacyShading = true;
+        RenderImage imgL;
+        imgL.Init(cam.imgWidth, cam.imgHeight);
+        rl.CastRays(imgL);
+        rtx_render_params rl_p = rp;
+        rl_p.spp_min = rl_p.spp_max = 4;
+        rl_p.shading_mode = RTX_SHADING_LEGACY;
+        std::vector<float> linL(np * 3);
+        orc_render(osc, &ocam, &rl_p, nullptr, 4, 1, nullptr, nullptr, nullptr, nullptr, nullptr, linL.data(), nullptr, nullptr, nullptr);
+        double seL = 0, meanL = 0, diffModes = 0;
+        for (size_t i = 0; i < np; ++i) {
+            const Color& g = imgL.GetLinearPixels()[i];
+            seL += std::pow(g.r - linL[3 * i], 2) + std::pow(g.g - linL[3 * i + 1], 2) + std::pow(g.b - linL[3 * i + 2], 2);
+            meanL += linL[3 * i] + linL[3 * i + 1] + linL[3 * i + 2];
+            diffModes += std::fabs(g.r - img.GetLinearPixels()[i].r);
+        }
+        const double rmseL = std::sqrt(seL / (3 * np));
+        meanL /= 3 * np;
+        CHECK(rmseL <= 0.02 * meanL, "legacy CastRays: rmse %.5f mean %.5f", rmseL, meanL);
+        if (rmseL > 0.02 * meanL) {   // where the frames differ most
+            std::vector<std::pair<float, size_t>> worst;
+            for (size_t i = 0; i < np; ++i) {
+                const Color& g = imgL.GetLinearPixels()[i];
+                worst.push_back({std::max(std::fabs(g.r - linL[3 * i]), std::max(std::fabs(g.g - linL[3 * i + 1]), std::fabs(g.b - linL[3 * i + 2]))), i});
+            }
+            std::sort(worst.rbegin(), worst.rend());
+            int nbig = 0;
+            for (auto& w : worst) nbig += w.first > 0.01f;
+            std::printf("  pixels off by > 0.01: %d\n", nbig);
+            for (int k = 0; k < 8; ++k) {
+                const size_t i = worst[k].second;
+                const Color& g = imgL.GetLinearPixels()[i];
+                std::printf("  (%3zu,%3zu) gpu %.4f %.4f %.4f  oracle %.4f %.4f %.4f\n", i % 96, i / 96, g.r, g.g, g.b, linL[3 * i], linL[3 * i + 1], linL[3 * i + 2]);
+            }
+        }
+        CHECK(diffModes / np > 1e-3, "legacy and path frames differ");
+
+        ShadeInfoAdapter si(scene.lights, &scene);
+        HitInfo fh; fh.Init(); fh.p = Vec3f(0.2f, 0.0f, 0.3f); fh.N = Vec3f(0, 1, 0); fh.node = nullptr;
+        si.SetHit(Ray(Vec3f(0, 3, 0), Vec3f(0, -1, 0)), fh);
+        si.SetPixel(5, 7); si.SetPixelSample(2); si.imageWidth = cam.imgWidth; si.bounce = 1; si.rngNode = 1;
+        rtx_shade_point at{};
+        at.P[0] = fh.p.x; at.P[1] = fh.p.y; at.P[2] = fh.p.z; at.N[1] = 1.0f;
+        at.obj = -1; at.bounce = 1; at.diffuse_depth = 0; at.pixel = 7 * cam.imgWidth + 5; at.sample = 2; at.node = 1;
+        int bad = 0, hits = 0;
+        std::mt19937 gen(3);
+        std::uniform_real_distribution<float> U(-1.0f, 1.0f);
+        for (int k = 0; k < 64; ++k) {
+            const Vec3f d(U(gen), std::fabs(U(gen)) + 0.05f, U(gen));
+            float dist = 0, ref[4];
+            const Color col = si.TraceSecondaryRay(d, dist, true);
+            const float dd[3] = {d.x, d.y, d.z};
+            orc_trace_secondary(osc, nullptr, &at, dd, 1, 1, 2, si.seed, ref);
+            const float tol = 2e-3f * (1.0f + std::max(ref[0], std::max(ref[1], ref[2])));
+            if (std::fabs(col.r - ref[0]) > tol || std::fabs(col.g - ref[1]) > tol || std::fabs(col.b - ref[2]) > tol) ++bad;
+            if ((dist > 1e29f) != (ref[3] > 1e29f) || (ref[3] < 1e29f && std::fabs(dist - ref[3]) > 1e-4f * (1 + ref[3]))) ++bad;
+            if (ref[3] < 1e29f) ++hits;
+        }
+        CHECK(bad <= 1 && hits > 5, "TraceSecondaryRay vs oracle: %d of 64 differ (%d hit geometry)", bad, hits);
+        si.bounce = 5;
+        float dist = 0;
+        const Color none = si.TraceSecondaryRay(Vec3f(0, 1, 0), dist);
+        CHECK(none.r == 0 && none.g == 0 && none.b == 0 && dist > 1e29f, "CanBounce stops the recursion");
+    }
 
     // photon map through the mirrored builder
     PhotonMapBuilder pmb;

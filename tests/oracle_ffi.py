@@ -71,6 +71,13 @@ class OracleScene:
                                     int(use_transmittance), _vp(vis.ctypes.data))
         return vis
 
+    def trace_secondary(self, at, dirs, recursive=True, child=2, seed=0x9E3779B97F4A7C15, photons=None):
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros((dirs.shape[0], 4), np.float32)
+        self.L.orc_trace_secondary(self.h, photons.h if photons else None, C.byref(at), _vp(dirs.ctypes.data),
+                                   C.c_size_t(dirs.shape[0]), int(recursive), child, C.c_uint64(seed), _vp(out.ctypes.data))
+        return out
+
     def render_primary(self, cam, hit_side=_ffi.HIT_FRONT, use_bvh=True, counters=False):
         n = cam.width * cam.height
         prim = np.zeros(n, dtype=np.int32)

@@ -101,3 +101,31 @@ def test_materials_and_objects(rtx):
     assert np.isfinite(g).all()
     assert frac_within(g, o) >= 0.995
     assert o[..., :3].max() > 0.5
+
+
+def test_trace_secondary_entry_point(small):
+    """rtx_trace_secondary = ShadeInfoAdapter::TraceSecondaryRay called from outside Shade(): colour and dist of 4096
+    rays from a point on the table, recursive and single-hit (recursive = false, :220-223), and the depth limit."""
+    sd, cam, gs, osc = small
+    rng = np.random.default_rng(11)
+    d = rng.normal(size=(4096, 3)).astype(np.float32)
+    d[:, 1] = np.abs(d[:, 1]) + 0.05
+    at = _ffi.ShadePoint()
+    at.P[:] = (0.9, 0.35, 0.2)
+    at.N[:] = (0.0, 1.0, 0.0)
+    at.obj, at.bounce, at.diffuse_depth, at.pixel, at.sample, at.node = -1, 1, 0, 1234, 3, 2
+    for recursive in (True, False):
+        g = gs.trace_secondary(at, d, recursive=recursive, child=2)
+        o = osc.trace_secondary(at, d, recursive=recursive, child=2)
+        assert np.isfinite(g[:, :3]).all()
+        big = o[:, 3] > 1e29
+        assert np.array_equal(g[:, 3] > 1e29, big)
+        assert (np.abs(g[~big, 3] - o[~big, 3]) <= 1e-4 * (1 + o[~big, 3])).mean() >= 0.999
+        assert frac_within(g, o) >= 0.995
+        assert (~big).sum() > 100 and o[:, :3].max() > 0
+    single = osc.trace_secondary(at, d, recursive=False, child=2)
+    full = osc.trace_secondary(at, d, recursive=True, child=2)
+    assert np.abs(single[:, :3] - full[:, :3]).max() > 1e-3      # the recursion does add light
+    at.bounce = 5                                                 # CanBounce false: black, dist = BIGFLOAT (:95-97)
+    g = gs.trace_secondary(at, d[:8])
+    assert np.all(g[:, :3] == 0) and np.all(g[:, 3] > 1e29)
