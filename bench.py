@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--samples-per-pass", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=96)
+    ap.add_argument("--legacy", action="store_true",
+                    help="legacy shading mode (SHADING_USE_LEGACY=1) instead of the headline path-traced configuration")
     return ap.parse_args()
 
 
@@ -77,7 +79,9 @@ def main():
     info = scene.info()
     W, H = a.width, a.height
     tens, film = make_film(W, H, dev)
-    rp = render_params(spp_min=a.spp, max_bounces=a.max_bounces, rank=rank, world=world, samples_per_pass=a.samples_per_pass)
+    mode = _ffi.SHADING_LEGACY if a.legacy else _ffi.SHADING_PATH
+    rp = render_params(spp_min=a.spp, max_bounces=a.max_bounces, rank=rank, world=world, samples_per_pass=a.samples_per_pass,
+                       shading_mode=mode)
 
     def step():
         ra.film_clear(film, W, H)
@@ -92,11 +96,12 @@ def main():
 
     # algorithmic bytes per extend ray from an instrumented (counting) pass at 2 spp, untimed
     scene.set_counters(True)
-    rp_c = render_params(spp_min=2, max_bounces=a.max_bounces, rank=rank, world=world)
+    rp_c = render_params(spp_min=2, max_bounces=a.max_bounces, rank=rank, world=world, shading_mode=mode)
     ra.film_clear(film, W, H)
     stc = scene.render_accumulate(cam, rp_c, film)
     scene.set_counters(False)
-    ext_rays_c = stc["rays_primary"] + stc["rays_bounce"]
+    # rays traced by extend_kernel launches (legacy mode: the primary rays; its secondary rays run inside legacy_kernel)
+    ext_rays_c = stc["rays_primary"] + (0 if a.legacy else stc["rays_bounce"])
     nodes_per_ray = stc["nodes_visited"] / max(1, ext_rays_c)
     tris_per_ray = stc["tris_tested"] / max(1, ext_rays_c)
     bytes_per_ray = 32 + 16 + nodes_per_ray * info["node_bytes"] + tris_per_ray * info["tri_bytes"]
@@ -109,7 +114,7 @@ def main():
     for _ in range(a.steps):
         st = step()
         agg["rays"] += st["rays_primary"] + st["rays_bounce"] + st["rays_shadow"]
-        agg["ext_rays"] += st["rays_primary"] + st["rays_bounce"]
+        agg["ext_rays"] += st["rays_primary"] + (0 if a.legacy else st["rays_bounce"])
         agg["shadow_rays"] += st["rays_shadow"]
         agg["extend_ms"] += st["extend_ms"]
         agg["shadow_ms"] += st["shadow_ms"]
@@ -144,7 +149,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"C3: cerealbar-synth {W}x{H} {a.spp} spp path tracing max_bounces={a.max_bounces}",
+            "config": {"workload": (f"legacy shading mode: cerealbar-synth {W}x{H} {a.spp} spp, Whitted recursion depth 5" if a.legacy else
+                                    f"C3: cerealbar-synth {W}x{H} {a.spp} spp path tracing max_bounces={a.max_bounces}"),
                        "triangles": info["triangles"], "bvh_nodes": info["nodes"], "tri_scale": a.tri_scale,
                        "parallelism": f"tile-sharded x{world}, scene replicated, film reduce over RCCL"},
             "rays_per_frame": rays_all / a.steps,
@@ -173,7 +179,7 @@ def measured_traffic(a, world):
     launches. A PMC run cannot be nested inside this process, so the figure is the committed measurement; it is
     reported only when this run is the configuration it was measured on."""
     path = os.path.join(ROOT, "profiles", "r01", "extend_traffic_c3.json")
-    default = (a.tri_scale == 1.0 and a.width == 1920 and a.height == 1080 and a.spp == 128 and a.max_bounces == 64 and
+    default = (not a.legacy and a.tri_scale == 1.0 and a.width == 1920 and a.height == 1080 and a.spp == 128 and a.max_bounces == 64 and
                world == 1)
     if not default or not os.path.exists(path):
         return None, None
@@ -191,7 +197,8 @@ def cpu_baseline(sd, cam, a):
     t0 = time.perf_counter()
     osc = OracleScene(sd)
     build_s = time.perf_counter() - t0
-    rp = render_params(spp_min=a.cpu_spp, max_bounces=a.max_bounces)
+    rp = render_params(spp_min=a.cpu_spp, max_bounces=a.max_bounces,
+                       shading_mode=_ffi.SHADING_LEGACY if a.legacy else _ffi.SHADING_PATH)
     r = osc.render(cam, rp, nthreads=threads, subset_stride=8)
     rays = r["rays"]["primary"] + r["rays"]["bounce"] + r["rays"]["shadow"]
     return {"value": rays / r["seconds"] / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",

@@ -107,3 +107,22 @@ def test_sphere_light_seen_by_secondary_ray_is_clamped():
     cam = make_camera((0.0, 1.0, 0.001), (0, 3, 0), (0, 0, -1), fov=4, width=4, height=4)   # looking at the light itself
     s = OracleScene(sd).render_samples(cam, legacy())
     assert s[2, 2, 0, 0] == pytest.approx(I / (np.pi * r * r), rel=1e-5)
+
+
+def test_golden_legacy_fixture():
+    """tests/golden/legacy_small.npz (tools/make_golden.py legacy): the oracle reproduces its committed outputs."""
+    import os
+    from raytracer_amd import synth
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "legacy_small.npz"))
+    osc = OracleScene(synth.build_scene(0.002))
+    cam = synth.cerealbar_camera(48, 27)
+    rp = legacy(4)
+    assert np.allclose(osc.render_samples(cam, rp), g["samples"], rtol=1e-6, atol=1e-7)
+    img = osc.render(cam, rp)
+    assert np.allclose(img["linear"], g["linear"], rtol=1e-5, atol=1e-6)
+    assert [img["rays"][k] for k in ("primary", "bounce", "shadow")] == list(g["rays"])
+    at = _ffi.ShadePoint()
+    at.P[:] = (0.9, 0.35, 0.2)
+    at.N[:] = (0.0, 1.0, 0.0)
+    at.obj, at.bounce, at.diffuse_depth, at.pixel, at.sample, at.node = -1, 1, 0, 77, 1, 1
+    assert np.allclose(osc.trace_secondary(at, g["dirs"], recursive=True, child=1), g["secondary"], rtol=1e-6, atol=1e-7)

@@ -129,3 +129,19 @@ def test_trace_secondary_entry_point(small):
     at.bounce = 5                                                 # CanBounce false: black, dist = BIGFLOAT (:95-97)
     g = gs.trace_secondary(at, d[:8])
     assert np.all(g[:, :3] == 0) and np.all(g[:, 3] > 1e29)
+
+
+def test_golden_legacy_fixture(rtx):
+    """The committed oracle fixture (tools/make_golden.py legacy) on the GPU box without running the oracle."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "legacy_small.npz"))
+    gs = rtx.Scene(synth.build_scene(0.002))
+    cam = synth.cerealbar_camera(48, 27)
+    s, _ = gs.render_samples(cam, render_params(spp_min=4, shading_mode=LEGACY))
+    assert frac_within(s, g["samples"]) >= 0.995
+    at = _ffi.ShadePoint()
+    at.P[:] = (0.9, 0.35, 0.2)
+    at.N[:] = (0.0, 1.0, 0.0)
+    at.obj, at.bounce, at.diffuse_depth, at.pixel, at.sample, at.node = -1, 1, 0, 77, 1, 1
+    sec = gs.trace_secondary(at, g["dirs"], recursive=True, child=1)
+    assert frac_within(sec, g["secondary"]) >= 0.995
