@@ -184,8 +184,15 @@ struct Emitter {
         // e1 = v1 - v0, e2 = v2 - v0 in fp32: the operands the reference forms per test (objects.cpp:146-147)
         r.e1x = t.v[1][0] - t.v[0][0]; r.e1y = t.v[1][1] - t.v[0][1]; r.e1z = t.v[1][2] - t.v[0][2];
         r.e2x = t.v[2][0] - t.v[0][0]; r.e2y = t.v[2][1] - t.v[0][1]; r.e2z = t.v[2][2] - t.v[0][2];
+        // opaque for shadow rays: no material, or max(Refraction().GetValue()) <= 0 (RayCaster.cpp:215-229)
+        const int objMtl = desc->meshes[t.obj].material;
+        bool opaque = true;
+        if (objMtl >= 0 && objMtl < desc->n_materials) {
+            const float* kt = desc->materials[objMtl].refraction;
+            opaque = !(std::max(kt[0], std::max(kt[1], kt[2])) > 0.0f);
+        }
         r.kind = (uint32_t)t.kind;
-        r.obj = (uint32_t)t.obj;
+        r.obj = (uint32_t)t.obj | (opaque ? TRI_OPAQUE : 0u);
         r.prim = (uint32_t)(faceBase[t.obj] + t.face);
         out.tris.push_back(r);
         if (t.kind != RTX_OBJ_MESH) {

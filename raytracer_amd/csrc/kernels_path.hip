@@ -148,6 +148,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
 #ifndef LEAF_WEIGHT
 #define LEAF_WEIGHT 1u
 #endif
+#ifndef SHADOW_ANYHIT
+#define SHADOW_ANYHIT 1
+#endif
 #ifndef SHADOW_REFILL_MIN
 #define SHADOW_REFILL_MIN 16
 #endif
@@ -218,7 +221,19 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene sc, PathPoo
             const bool atLeaf = active && !atInner && s.cur != RTX_TRAV_DONE;
             const uint32_t nInner = (uint32_t)__popcll(__ballot(atInner)), nLeaf = (uint32_t)__popcll(__ballot(atLeaf));
             if (nLeaf * LEAF_WEIGHT >= nInner) {
-                if (atLeaf) trav_leaf_step(s, sc, st, RTX_HIT_FRONT_AND_BACK);
+                if (atLeaf) {
+#if SHADOW_ANYHIT
+                    const int before = s.best.slot;
+                    trav_leaf_test(s, sc, s.cur, RTX_HIT_FRONT_AND_BACK);
+                    if (s.best.slot != before && shadow_hit_decides(sc, s, maxDist, useTransmittance != 0)) {
+                        s.cur = RTX_TRAV_DONE;   // the chain ends with 0 at this blocker (shadow_hop_end)
+                        s.sp = 0;
+                    } else
+                        trav_pop(s, st);
+#else
+                    trav_leaf_step(s, sc, st, RTX_HIT_FRONT_AND_BACK);
+#endif
+                }
             } else if (atInner)
                 trav_inner_step(s, sc, st);
         }

@@ -42,9 +42,12 @@ struct TriRec {
     uint32_t kind;          // 0 = triangle; RTX_OBJ_SPHERE / RTX_OBJ_PLANE: analytic object, then v0 = world box
                             // min, e1 = e2 = box extent (so v0, v0+e1 span its box) and `obj` names its transform
     float e2x, e2y, e2z;
-    uint32_t obj;           // object index (analytic records only)
+    uint32_t obj;           // object index (read for analytic records only) | TRI_OPAQUE: the object's material lets no
+                            // light through (Visible() returns 0 at it). Kept out of `kind`, which the triangle test reads.
 };
 static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+#define TRI_OBJ_MASK 0x7FFFFFFFu
+#define TRI_OPAQUE 0x80000000u
 
 struct TriAttr {
     float n0[3], n1[3], n2[3];

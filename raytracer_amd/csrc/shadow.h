@@ -18,7 +18,7 @@ __device__ __forceinline__ void triangle_gn(const DevScene& sc, const RayT& r, i
     const float4 c = tris4[(size_t)slot * 3 + 2];
     if (__float_as_uint(b.w) != 0u) {   // Sphere / Plane
         SurfHit sh;
-        resolve_analytic(sc, __float_as_uint(b.w), __float_as_uint(c.w), r, HitT{t, 0.0f, 0.0f, slot}, sh);
+        resolve_analytic(sc, __float_as_uint(b.w), __float_as_uint(c.w) & TRI_OBJ_MASK, r, HitT{t, 0.0f, 0.0f, slot}, sh);
         GN = sh.GN;
         front = sh.front;
         obj = sh.obj;
@@ -74,6 +74,31 @@ __device__ __forceinline__ bool shadow_hop_end(const DevScene& sc, f3& o, f3 d, 
     }
     ++hop;
     return hop >= 8;   // kMaxHops with transmittance: the chain gives up with 0
+}
+
+// Early end of a shadow hop: the hit just accepted (s.best) already decides the whole chain when it is a blocker
+// that no later hop can get past - an opaque surface (any surface for VisibleSimple) in front of the segment's end
+// and of every renderable light. Closer hits can only be transmissive ones, whose hops continue towards the same
+// blocker (or give up with 0 themselves, :268-276), so Visible() returns 0 and the rest of the traversal is not
+// needed. The margins keep hits within rounding of the segment end or of a light surface on the full path.
+__device__ __forceinline__ bool shadow_hit_decides(const DevScene& sc, const TravState& s, float maxDist, bool useTransmittance) {
+    if (s.best.slot < 0) return false;
+    if (!(s.best.t < (maxDist - 1e-4f) * 0.99999f)) return false;
+    if (useTransmittance && (sc.tris[s.best.slot].obj & TRI_OPAQUE) == 0u) return false;
+    for (int i = 0; i < sc.n_lights; ++i) {
+        const DevLight& L = sc.lights[i];
+        if (L.size <= 0.0f) continue;
+        // conservative: a light whose sphere the ray enters before (or near) the hit keeps the full path
+        const float ocx = s.r.ox - L.pos[0], ocy = s.r.oy - L.pos[1], ocz = s.r.oz - L.pos[2];
+        const float b = ocx * s.r.dx + ocy * s.r.dy + ocz * s.r.dz;
+        const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - L.size * L.size;
+        const float disc = b * b - c;
+        if (disc < 0.0f) continue;
+        const float root = sqrtf(disc);
+        if (-b + root < 0.0f) continue;                       // sphere wholly behind the origin
+        if (-b - root <= s.best.t * 1.00001f) return false;   // entered (or origin inside) before the hit
+    }
+    return true;
 }
 
 // o = OffsetPoint(origin, normal, dir), d = SafeNormalize(dir) already applied (RayCaster.cpp:199)

@@ -121,7 +121,7 @@ __device__ __forceinline__ void resolve_triangle(const DevScene& sc, const RayT&
     const float4 b = tris4[(size_t)h.slot * 3 + 1];
     const float4 c = tris4[(size_t)h.slot * 3 + 2];
     if (__float_as_uint(b.w) != 0u) {
-        resolve_analytic(sc, __float_as_uint(b.w), __float_as_uint(c.w), r, h, s);
+        resolve_analytic(sc, __float_as_uint(b.w), __float_as_uint(c.w) & TRI_OBJ_MASK, r, h, s);
         return;
     }
     const float4* at4 = reinterpret_cast<const float4*>(sc.attrs + h.slot);

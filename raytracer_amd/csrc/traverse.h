@@ -155,7 +155,7 @@ __device__ __forceinline__ void test_analytic(const DevScene& sc, uint32_t kind,
 __device__ __forceinline__ void test_primitive(const DevScene& sc, const float4 a, const float4 b, const float4 c, const RayT& r,
                                                int hitSide, uint32_t slot, HitT& best, uint32_t& bestPrim) {
     const uint32_t kind = __float_as_uint(b.w);
-    if (kind != 0u) test_analytic(sc, kind, __float_as_uint(c.w), __float_as_uint(a.w), r, hitSide, slot, best, bestPrim);
+    if (kind != 0u) test_analytic(sc, kind, __float_as_uint(c.w) & TRI_OBJ_MASK, __float_as_uint(a.w), r, hitSide, slot, best, bestPrim);
     else test_triangle(a, b, c, r, hitSide, slot, sc.tris, best, bestPrim);
 }
 
