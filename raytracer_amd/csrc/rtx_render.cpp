@@ -18,7 +18,21 @@ struct PathPoolHost {
     bool hasCaustic = false;
     std::vector<hipEvent_t> events;
     size_t bytes = 0;
+    // second stream: the shadow + resolve kernels of bounce k run beside the extend kernel of bounce k+1
+    hipStream_t sideStream = nullptr;
+    hipEvent_t sideDone = nullptr;
+    uint2* sideSpill = nullptr;   // its own traversal spill slab (both kernels are in flight at once)
     void release() {
+        if (sideStream) {
+            (void)hipStreamSynchronize(sideStream);
+            (void)hipStreamDestroy(sideStream);
+            sideStream = nullptr;
+        }
+        if (sideDone) {
+            (void)hipEventDestroy(sideDone);
+            sideDone = nullptr;
+        }
+        sideSpill = nullptr;   // in allocs
         for (void* p : allocs) (void)hipFree(p);
         allocs.clear();
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
@@ -274,6 +288,24 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     if (const char* e = std::getenv("RTX_AMD_TAIL_PATHS")) tailMax = std::min<uint32_t>(tailMax, (uint32_t)std::atol(e));   // 0 disables
     if (s->cfg.counting) tailMax = 0;   // node / triangle tallies exist in the counting build of extend_kernel only
 
+    // Overlap: shadow(k) + resolve(k) on a side stream beside extend(k+1); shade(k+1) waits for both. Either kernel
+    // alone leaves most of the chip idle while its last rays finish (a launch costs ~0.3 ms beyond its throughput time).
+    // Only for bounces of at most overlapMax paths: larger launches fill the chip on their own, and sharing it would
+    // stretch the extend launches that the roofline figure is measured on.
+    bool overlap = true;
+    uint32_t overlapMax = 2u << 20;
+    if (const char* e = std::getenv("RTX_AMD_OVERLAP")) overlap = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RTX_AMD_OVERLAP_MAX")) overlapMax = (uint32_t)std::atol(e);
+    if (overlap && !legacy && !ph->sideStream) {
+        RTX_HIP(hipStreamCreateWithFlags(&ph->sideStream, hipStreamNonBlocking));
+        RTX_HIP(hipEventCreateWithFlags(&ph->sideDone, hipEventDisableTiming));
+        if ((rc = pool_alloc(ph, &ph->sideSpill, (size_t)s->cfg.gridBlocks * TRAV_BLOCK * STACK_GLOBAL)) != RTX_OK) return rc;
+    }
+    LaunchCfg sideCfg = s->cfg;
+    sideCfg.stream = ph->sideStream;
+    sideCfg.spill = ph->sideSpill;
+    bool sidePending = false;   // a resolve on the side stream that the main stream has not waited for yet
+
     s->cancel.store(0);
     PassTimers tm{ph};
     int* curPixels = pool.pixels;
@@ -314,6 +346,10 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 launch_extend_queue(s->dev, s->cfg, pool.rays, sqIn, qin, n, RTX_HIT_FRONT_AND_BACK, 1, pool.hits);
                 tm.end(st);
                 out.extend_launches++;
+                if (sidePending) {
+                    RTX_HIP(hipStreamWaitEvent(st, ph->sideDone, 0));
+                    sidePending = false;
+                }
                 tm.begin(2, st);
                 const uint32_t gridShade = launch_shade(s->dev, dc, pool, pm, sqIn, qin, n, bounce, rp->max_bounces, rp->seed, sBase, Sp,
                                                         curPixels, sqOut, qout, pool.qS, s->hasMicrofacet, st);
@@ -322,17 +358,28 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 uint32_t cnt[2] = {0, 0};
                 RTX_HIP(hipMemcpyAsync(cnt, pool.totals, sizeof(cnt), hipMemcpyDeviceToHost, st));
                 RTX_HIP(hipStreamSynchronize(st));
+                // the host has synchronised the main stream: what goes to the side stream now runs after shade(k)
+                const bool side = overlap && cnt[0] > 0 && cnt[0] <= overlapMax;   // cnt[0] = 0: nothing to overlap with
+                hipStream_t sst = side ? ph->sideStream : st;
                 if (cnt[1]) {
-                    tm.begin(1, st);
-                    launch_shadow(s->dev, s->cfg, pool, pool.qS, cnt[1], bounce <= 8 ? 1 : 0);   // useTransmittance (RayCaster.cpp:454)
-                    tm.end(st);
+                    tm.begin(1, sst);
+                    launch_shadow(s->dev, side ? sideCfg : s->cfg, pool, pool.qS, cnt[1], bounce <= 8 ? 1 : 0);   // useTransmittance (RayCaster.cpp:454)
+                    tm.end(sst);
                 }
-                launch_resolve(pool, sqIn, qin, n, s->dev.n_lights, usePhotons ? 1 : 0, st);
+                launch_resolve(pool, sqIn, qin, n, s->dev.n_lights, usePhotons ? 1 : 0, sst);
+                if (side) {
+                    RTX_HIP(hipEventRecord(ph->sideDone, ph->sideStream));
+                    sidePending = true;
+                }
                 std::swap(qin, qout);
                 std::swap(sqIn, sqOut);
                 n = cnt[0];
                 if (n > 0 && n <= tailMax && bounce + 1 < rp->max_bounces) {
                     // few paths left: one kernel walks them to their ends (tail_kernel)
+                    if (sidePending) {
+                        RTX_HIP(hipStreamWaitEvent(st, ph->sideDone, 0));
+                        sidePending = false;
+                    }
                     tm.begin(2, st);
                     launch_tail(s->dev, s->cfg, dc, pool, pm, sqIn, qin, n, bounce + 1, rp->max_bounces, rp->seed, sBase, Sp, curPixels,
                                 s->hasMicrofacet);
@@ -341,8 +388,13 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 }
                 if (tm.spans.size() > 2048) {
                     RTX_HIP(hipStreamSynchronize(st));
+                    if (ph->sideStream) RTX_HIP(hipStreamSynchronize(ph->sideStream));
                     tm.flush();
                 }
+            }
+            if (sidePending) {   // a cancelled pass, or max_bounces reached with paths alive
+                RTX_HIP(hipStreamWaitEvent(st, ph->sideDone, 0));
+                sidePending = false;
             }
             // a pass interrupted by rtx_cancel holds unfinished paths: it is dropped, earlier passes stay
             if (!s->cancel.load(std::memory_order_relaxed))
