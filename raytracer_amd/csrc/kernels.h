@@ -63,7 +63,7 @@ uint32_t launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& 
 #define RTX_TAIL_MAX_PATHS 65536u
 void launch_tail(const DevScene& sc, const LaunchCfg& cfg, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm,
                  const SegQ& qIn, const uint32_t* queueIn, uint32_t n, int bounce0, int maxBounces, unsigned long long seed, int sBase,
-                 int S, const int* pixels, int hasMicrofacet);
+                 int S, const int* pixels, int hasMicrofacet, int usePhotons);
 void launch_shadow(const DevScene& sc, const LaunchCfg& cfg, const PathPool& pool, const SegQ& q, uint32_t n, int useTransmittance);
 void launch_resolve(const PathPool& pool, const SegQ& qIn, const uint32_t* queueIn, uint32_t n, int nLights, int usePhotons,
                     hipStream_t stream);

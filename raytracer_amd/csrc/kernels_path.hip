@@ -131,10 +131,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
         slot = queueIn[segq_item_index(qtab, i)];
         const float4 ra = pool.rays[2 * (size_t)slot], rb = pool.rays[2 * (size_t)slot + 1];
         const float4 hv = pool.hits[slot];
-        uint32_t hops = 0;
         alive = shade_body<MICRO, false>(sc, cam, pool, pm, slot, RayT{ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, ra.w},
-                                         HitT{hv.x, hv.y, hv.z, __float_as_int(hv.w)}, bounce, maxBounces, seed, sBase, S, pixels, qShadow,
-                                         TravStack{nullptr, nullptr, 0u}, hops);
+                                         HitT{hv.x, hv.y, hv.z, __float_as_int(hv.w)}, bounce, maxBounces, seed, sBase, S, pixels, qShadow);
     }
     // ---- surviving paths -> next queue ----
     const uint32_t q = segq_append(qOut, alive, 1u);
@@ -249,29 +247,7 @@ __global__ void resolve_kernel(PathPool pool, SegQ qIn, const uint32_t* __restri
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t slot = queueIn[segq_item_index(qtab, i)];
-    const float4 pb = pool.pendBeta[slot];
-    if (pb.w < 0.0f) return;
-    const f3 beta = mk3(pb.x, pb.y, pb.z);
-    float4 L4 = pool.L[slot];
-    f3 L = mk3(L4.x, L4.y, L4.z);
-    f3 direct = mk3(0.0f);
-    float maxVisibility = 0.0f;
-    for (int l = 0; l < nLights; ++l) {
-        const float4 c = pool.nee[(size_t)l * pool.capacity + slot];
-        if (c.w < 0.0f) continue;
-        maxVisibility = fmaxf(maxVisibility, c.w);
-        if (c.w <= 0.0f) continue;
-        direct = direct + mk3(c.x, c.y, c.z) * c.w;
-    }
-    if (max3c(direct) > 0.0f) L = L + beta * direct;
-    if (usePhotons) {
-        const float4 cz = pool.caustic[slot];
-        if (cz.w > 0.0f) {
-            const float causticScale = 0.1f + 0.9f * maxVisibility;
-            L = L + beta * (mk3(cz.x, cz.y, cz.z) * causticScale);
-        }
-    }
-    pool.L[slot] = make_float4(L.x, L.y, L.z, L4.w);
+    resolve_slot(pool, slot, nLights, usePhotons);
 }
 
 // ---- film (RayCaster.cpp:798-838) -----------------------------------------------------------------------------

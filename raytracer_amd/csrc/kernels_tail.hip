@@ -5,46 +5,121 @@
 
 // The tail of a pass: once few paths are left (deep bounces of glass / mirror chains), a bounce costs the latency of
 // its longest ray three times over (extend, shade, shadow launches plus a host round trip), whatever the count. Here
-// one lane walks one path to its end - closest hit, shading, NEE visibility and its resolve - without leaving the
-// kernel, so the remaining bounces cost one path's own latency instead of a launch sequence each.
+// FOUR lanes walk one path to its end without leaving the kernel. All four run the shading body on the same inputs
+// (same results, same stores); what they share out are the traversals, which are independent of one another and are
+// the latency that counts: lane 0 traces the next ray of the path while lanes 1..3 trace the shadow chains of the
+// vertex just shaded (rounds of four jobs when the scene has more than three lights). Every job is a chain of
+// closest hits through one loop - the extend job is a chain that ends after its first hop - so the four lanes stay in
+// one instruction stream. Results go round the quad by shuffles; each lane then writes the transmittances and runs
+// the same resolve as resolve_kernel, so a lane only ever reads what it has written itself.
 template <bool MICRO>
 __global__ __launch_bounds__(TRAV_BLOCK) void tail_kernel(DevScene sc, DevCamera cam, PathPool pool, DevPhotonMap pm, SegQ qIn,
                                                           const uint32_t* __restrict__ queueIn, uint32_t n, int bounce0, int maxBounces,
                                                           unsigned long long seed, int sBase, int S, const int* __restrict__ pixels,
-                                                          uint2* spill) {
+                                                          int usePhotons, uint2* spill) {
     __shared__ uint32_t qtab[SEGQ_TABLE_WORDS];
     __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
     segq_load_table(qIn, qtab);
     __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    TravStack st{&lds_stack[threadIdx.x], spill + i, gridDim.x * blockDim.x};
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t q = gtid & 3u, path = gtid >> 2;
+    const int quadBase = (int)(threadIdx.x & 63u & ~3u);
+    TravStack st{&lds_stack[threadIdx.x], spill + gtid, gridDim.x * blockDim.x};
+    const int nL = sc.n_lights;
+    const uint32_t cap = pool.capacity, mult = (uint32_t)max(1, nL);
     uint32_t hops = 0, rays = 0;
-    if (i < n) {
-        const uint32_t slot = queueIn[segq_item_index(qtab, i)];
-        for (int bounce = bounce0; bounce < maxBounces; ++bounce) {
+    const bool valid = path < n;
+    const uint32_t slot = valid ? queueIn[segq_item_index(qtab, path)] : 0u;
+    bool needExtend = valid;    // the path's next ray waits in pool.rays[slot]
+    bool haveVertex = false;    // the NEE of the vertex shaded last waits for its shadow results
+    int bounce = bounce0;       // bounce index of that next ray
+    while (needExtend || haveVertex) {
+        RayT ray{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f};
+        if (needExtend) {
             const float4 ra = pool.rays[2 * (size_t)slot], rb = pool.rays[2 * (size_t)slot + 1];
-            const RayT ray{ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, ra.w};
-            uint32_t nc = 0, tc = 0;
-            HitT h = traverse_closest<false>(sc, ray, RTX_HIT_FRONT_AND_BACK, st, &nc, &tc);
-            intersect_lights(sc, ray, h);
-            ++rays;
-            if (!shade_body<MICRO, true>(sc, cam, pool, pm, slot, ray, h, bounce, maxBounces, seed, sBase, S, pixels, SegQ{nullptr}, st, hops))
-                break;
+            ray = RayT{ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, ra.w};
+        }
+        HitT hit{RTX_BIG, 0.0f, 0.0f, -1};
+        const int nJobs = 1 + (haveVertex ? nL : 0);
+        const bool useTransmittance = (bounce - 1) <= 8;   // of the vertex whose shadows are traced (RayCaster.cpp:454)
+        for (int r = 0; r * 4 < nJobs; ++r) {
+            const int j = r * 4 + (int)q;
+            const bool isExtend = j == 0;
+            bool act = false;
+            f3 o = mk3(0.0f), d = mk3(0.0f, 0.0f, 1.0f);
+            float maxDist = 0.0f;
+            if (isExtend) {
+                if (needExtend) {
+                    o = mk3(ray.ox, ray.oy, ray.oz);
+                    d = mk3(ray.dx, ray.dy, ray.dz);
+                    maxDist = ray.tmax;
+                    act = true;
+                }
+            } else if (haveVertex && j - 1 < nL) {
+                if (pool.nee[(size_t)(j - 1) * cap + slot].w >= 0.0f) {
+                    const size_t e = (size_t)slot * mult + (size_t)(j - 1);
+                    const float4 a = pool.shadowQ[2 * e], b = pool.shadowQ[2 * e + 1];
+                    o = mk3(a.x, a.y, a.z);
+                    d = mk3(b.x, b.y, b.z);
+                    maxDist = a.w;
+                    act = true;
+                }
+            }
+            // one chain of closest hits per lane
+            float visibility = 1.0f, result = 1.0f;
+            int hop = 0;
+            HitT h{RTX_BIG, 0.0f, 0.0f, -1};
+            bool running = act;
+            while (running) {
+                const RayT seg{o.x, o.y, o.z, d.x, d.y, d.z, maxDist};
+                uint32_t nc = 0, tc = 0;
+                h = traverse_closest<false>(sc, seg, RTX_HIT_FRONT_AND_BACK, st, &nc, &tc);
+                intersect_lights(sc, seg, h);
+                if (isExtend) {
+                    ++rays;
+                    running = false;
+                } else {
+                    ++hops;
+                    running = !shadow_hop_end(sc, o, d, maxDist, h, useTransmittance, hop, visibility, result);
+                }
+            }
+            // results round the quad
+            if (r == 0) {
+                hit.t = __shfl(h.t, quadBase);
+                hit.u = __shfl(h.u, quadBase);
+                hit.v = __shfl(h.v, quadBase);
+                hit.slot = __shfl(h.slot, quadBase);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float Tk = __shfl(result, quadBase + k);
+                const int ak = __shfl((int)act, quadBase + k);
+                const int jk = r * 4 + k;
+                if (jk >= 1 && ak) pool.nee[(size_t)(jk - 1) * cap + slot].w = Tk;
+            }
+        }
+        if (haveVertex) resolve_slot(pool, slot, nL, usePhotons);
+        haveVertex = false;
+        if (needExtend) {
+            needExtend = shade_body<MICRO, true>(sc, cam, pool, pm, slot, ray, hit, bounce, maxBounces, seed, sBase, S, pixels, SegQ{nullptr});
+            haveVertex = true;   // resolve_slot looks at the pending marker the body leaves
+            ++bounce;
         }
     }
+    if (q != 0u) rays = 0;   // hops are counted by the lane that traced them, the path's rays by lane 0
     atomicAdd(&pool.rayCounters[0], (unsigned long long)hops);
     atomicAdd(&pool.rayCounters[1], (unsigned long long)rays);
 }
 
 void launch_tail(const DevScene& sc, const LaunchCfg& cfg, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm,
                  const SegQ& qIn, const uint32_t* queueIn, uint32_t n, int bounce0, int maxBounces, unsigned long long seed, int sBase,
-                 int S, const int* pixels, int hasMicrofacet) {
+                 int S, const int* pixels, int hasMicrofacet, int usePhotons) {
     if (!n) return;
-    const uint32_t grid = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;   // n <= RTX_TAIL_MAX_PATHS <= gridBlocks * TRAV_BLOCK: inside the spill slab
+    const uint32_t grid = (4u * n + TRAV_BLOCK - 1) / TRAV_BLOCK;   // 4 lanes per path; 4n <= gridBlocks * TRAV_BLOCK: inside the spill slab
     if (hasMicrofacet)
         hipLaunchKernelGGL(tail_kernel<true>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, cam, pool, pm, qIn, queueIn, n, bounce0,
-                           maxBounces, seed, sBase, S, pixels, cfg.spill);
+                           maxBounces, seed, sBase, S, pixels, usePhotons, cfg.spill);
     else
         hipLaunchKernelGGL(tail_kernel<false>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, cam, pool, pm, qIn, queueIn, n, bounce0,
-                           maxBounces, seed, sBase, S, pixels, cfg.spill);
+                           maxBounces, seed, sBase, S, pixels, usePhotons, cfg.spill);
 }

@@ -6,6 +6,7 @@
 #include "pathstate.h"
 #include "photon.h"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -152,6 +153,9 @@ struct PassTimers {
     PathPoolHost* ph;
     size_t used = 0;
     std::vector<std::pair<int, std::pair<size_t, size_t>>> spans;   // kind, (start,stop) event index
+    std::vector<uint32_t> items;   // work items of each span (RTX_AMD_TRACE)
+    bool trace = std::getenv("RTX_AMD_TRACE") != nullptr;
+    uint32_t nextItems = 0;
     double ms[3] = {0, 0, 0};
     hipEvent_t get() {
         if (used == ph->events.size()) {
@@ -165,6 +169,7 @@ struct PassTimers {
         hipEvent_t e = get();
         (void)hipEventRecord(e, st);
         spans.push_back({kind, {used - 1, 0}});
+        if (trace) items.push_back(nextItems);
     }
     void end(hipStream_t st) {
         hipEvent_t e = get();
@@ -172,10 +177,16 @@ struct PassTimers {
         spans.back().second.second = used - 1;
     }
     void flush() {   // caller has synchronised the stream
+        size_t k = 0;
         for (auto& s : spans) {
             float t = 0.0f;
             if (hipEventElapsedTime(&t, ph->events[s.second.first], ph->events[s.second.second]) == hipSuccess) ms[s.first] += t;
+            if (trace) {   // development aid: one line per timed launch
+                static const char* names[3] = {"extend", "shadow", "shade/tail"};
+                std::fprintf(stderr, "[rtx trace] %-10s %10u items %9.3f ms\n", names[s.first], items[k++], t);
+            }
         }
+        items.clear();
         spans.clear();
         used = 0;
     }
@@ -284,7 +295,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     RTX_HIP(hipMemsetAsync(pool.qB.ctl, 0, SEGQ_WORDS * sizeof(uint32_t), st));
     RTX_HIP(hipMemsetAsync(pool.qS.ctl, 0, SEGQ_WORDS * sizeof(uint32_t), st));
     const uint32_t shadowMult = (uint32_t)std::max(1, s->dev.n_lights);
-    uint32_t tailMax = std::min<uint32_t>(RTX_TAIL_MAX_PATHS, (uint32_t)s->cfg.gridBlocks * TRAV_BLOCK);
+    uint32_t tailMax = std::min<uint32_t>(RTX_TAIL_MAX_PATHS, (uint32_t)s->cfg.gridBlocks * TRAV_BLOCK / 4u);   // 4 lanes per path
     if (const char* e = std::getenv("RTX_AMD_TAIL_PATHS")) tailMax = std::min<uint32_t>(tailMax, (uint32_t)std::atol(e));   // 0 disables
     if (s->cfg.counting) tailMax = 0;   // node / triangle tallies exist in the counting build of extend_kernel only
 
@@ -342,6 +353,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
             for (int bounce = 0; bounce < rp->max_bounces && n > 0 && !s->cancel.load(std::memory_order_relaxed); ++bounce) {
                 if (bounce == 0) out.rays_primary += n;
                 else out.rays_bounce += n;
+                tm.nextItems = n;
                 tm.begin(0, st);
                 launch_extend_queue(s->dev, s->cfg, pool.rays, sqIn, qin, n, RTX_HIT_FRONT_AND_BACK, 1, pool.hits);
                 tm.end(st);
@@ -362,6 +374,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 const bool side = overlap && cnt[0] > 0 && cnt[0] <= overlapMax;   // cnt[0] = 0: nothing to overlap with
                 hipStream_t sst = side ? ph->sideStream : st;
                 if (cnt[1]) {
+                    tm.nextItems = cnt[1];
                     tm.begin(1, sst);
                     launch_shadow(s->dev, side ? sideCfg : s->cfg, pool, pool.qS, cnt[1], bounce <= 8 ? 1 : 0);   // useTransmittance (RayCaster.cpp:454)
                     tm.end(sst);
@@ -380,9 +393,10 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                         RTX_HIP(hipStreamWaitEvent(st, ph->sideDone, 0));
                         sidePending = false;
                     }
+                    tm.nextItems = n;
                     tm.begin(2, st);
                     launch_tail(s->dev, s->cfg, dc, pool, pm, sqIn, qin, n, bounce + 1, rp->max_bounces, rp->seed, sBase, Sp, curPixels,
-                                s->hasMicrofacet);
+                                s->hasMicrofacet, usePhotons ? 1 : 0);
                     tm.end(st);
                     n = 0;
                 }

@@ -49,13 +49,13 @@ __device__ __forceinline__ bool has_map_or_value(const float* c, int tex) {   //
 // queueOut; NEE shadow segments are appended to the shadow queue; their results are folded in by resolve_kernel.
 // One vertex of one path: returns true when the path continues (its next ray is in pool.rays[slot]).
 // MICRO: the scene holds MtlMicrofacet materials (a second BSDF in the kernel; scenes without them run the leaner one).
-// TAIL: the caller is tail_kernel, which walks a path to its end inside one kernel: NEE visibility is traced on the
-// spot (st, hops) and folded into L here, in the order resolve_kernel would add it; nothing goes to the queues.
+// TAIL: the caller is tail_kernel, which walks a path to its end inside one kernel: the shadow segment of light l goes
+// to the fixed entry slot * lights + l of pool.shadowQ instead of the shadow queue; the kernel traces it and resolves.
 template <bool MICRO, bool TAIL>
 __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm,
                                            uint32_t slot, const RayT& ray, const HitT& h, int bounce, int maxBounces,
                                            unsigned long long seed, int sBase, int S, const int* __restrict__ pixels,
-                                           const SegQ& qShadow, TravStack st, uint32_t& hops) {
+                                           const SegQ& qShadow) {
     bool alive = false;
     const uint32_t cap = pool.capacity;
     const uint32_t shadowMult = (uint32_t)max(1, sc.n_lights);
@@ -161,8 +161,6 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
             // ---- next event estimation: contributions now, visibility by the shadow kernel (:456-503) ----
             const bool photonSurface = mtl_is_photon_surface(*mtl);
             const bool wantCaustic = pm.n > 0 && photonSurface;
-            f3 tailDirect = mk3(0.0f);
-            float tailMaxVis = 0.0f;
             for (int l = 0; l < sc.n_lights; ++l) {
                 const DevLight& light = sc.lights[l];
                 f3 ldir;
@@ -197,25 +195,15 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
                         pending = true;
                         const f3 so = offset_point(sh.p, sx.GN, ldir);
                         const f3 sd = safe_normalize3(ldir);
-                        if (TAIL) {
-                            uint32_t nc = 0, tc = 0;
-                            const float T = visible_chain_from<false>(sc, so, sd, shadowMax, bounce <= 8, st, &hops, &nc, &tc);
-                            tailMaxVis = fmaxf(tailMaxVis, T);
-                            if (T > 0.0f) tailDirect = tailDirect + c * T;
-                        } else {
-                            // wave-wide append of the lanes that reach this point (ballot counts active lanes only)
-                            const uint32_t qs = segq_append(qShadow, true, shadowMult);
-                            pool.shadowQ[2 * (size_t)qs] = make_float4(so.x, so.y, so.z, shadowMax);
-                            pool.shadowQ[2 * (size_t)qs + 1] = make_float4(sd.x, sd.y, sd.z, __uint_as_float(slot * 8u + (uint32_t)l));
-                        }
+                        // wave-wide append of the lanes that reach this point (ballot counts active lanes only)
+                        const uint32_t qs = TAIL ? slot * shadowMult + (uint32_t)l : segq_append(qShadow, true, shadowMult);
+                        pool.shadowQ[2 * (size_t)qs] = make_float4(so.x, so.y, so.z, shadowMax);
+                        pool.shadowQ[2 * (size_t)qs + 1] = make_float4(sd.x, sd.y, sd.z, __uint_as_float(slot * 8u + (uint32_t)l));
                     }
                 }
-                if (!TAIL) pool.nee[(size_t)l * cap + slot] = contrib;
+                pool.nee[(size_t)l * cap + slot] = contrib;
             }
-            if (TAIL) {
-                if (max3c(tailDirect) > 0.0f) L = L + beta * tailDirect;   // resolve_kernel, RayCaster.cpp:470-503
-            } else if (pending)
-                pool.pendBeta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
+            if (pending) pool.pendBeta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
 
             if (pm.n > 0) {   // :508-522 (scaled by the visibility in resolve_kernel)
                 float4 cz = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -226,12 +214,11 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
                         irrad = irrad * 0.1f;   // kCausticBoost
                         const f3 t = kd * (1.0f / PI_F) * irrad;
                         cz = make_float4(t.x, t.y, t.z, 1.0f);
-                        if (TAIL) L = L + beta * (t * (0.1f + 0.9f * tailMaxVis));   // resolve_kernel, RayCaster.cpp:518-520
-                        else if (!pending) pool.pendBeta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
+                        if (!pending) pool.pendBeta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
                         pending = true;
                     }
                 }
-                if (!TAIL) pool.caustic[slot] = cz;
+                pool.caustic[slot] = cz;
             }
 
             // ---- BSDF sampling for the next bounce (:525-566) ----
@@ -271,7 +258,7 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
         pool.L[slot] = make_float4(L.x, L.y, L.z, L4.w);
         pool.beta[slot] = make_float4(beta.x, beta.y, beta.z, lastPdf);
         pool.medium[slot] = make_float4(mediumAbs.x, mediumAbs.y, mediumAbs.z, __uint_as_float(flags));
-        if (!TAIL && !pending) {
+        if (!pending) {
             // mark "nothing to resolve" for resolve_kernel
             pool.pendBeta[slot] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
         }
@@ -279,3 +266,30 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
     return alive;
 }
 
+// L += beta * sum_i c_i T_i and the caustic term of one path vertex once its shadow results are in pool.nee[].w
+// (RayCaster.cpp:470-522), in the reference's order of additions into L.
+__device__ __forceinline__ void resolve_slot(const PathPool& pool, uint32_t slot, int nLights, int usePhotons) {
+    const float4 pb = pool.pendBeta[slot];
+    if (pb.w < 0.0f) return;
+    const f3 beta = mk3(pb.x, pb.y, pb.z);
+    float4 L4 = pool.L[slot];
+    f3 L = mk3(L4.x, L4.y, L4.z);
+    f3 direct = mk3(0.0f);
+    float maxVisibility = 0.0f;
+    for (int l = 0; l < nLights; ++l) {
+        const float4 c = pool.nee[(size_t)l * pool.capacity + slot];
+        if (c.w < 0.0f) continue;
+        maxVisibility = fmaxf(maxVisibility, c.w);
+        if (c.w <= 0.0f) continue;
+        direct = direct + mk3(c.x, c.y, c.z) * c.w;
+    }
+    if (max3c(direct) > 0.0f) L = L + beta * direct;
+    if (usePhotons) {
+        const float4 cz = pool.caustic[slot];
+        if (cz.w > 0.0f) {
+            const float causticScale = 0.1f + 0.9f * maxVisibility;
+            L = L + beta * (mk3(cz.x, cz.y, cz.z) * causticScale);
+        }
+    }
+    pool.L[slot] = make_float4(L.x, L.y, L.z, L4.w);
+}
