@@ -10,7 +10,7 @@
 //       <glossiness value>, <refraction index>, <absorption r g b>, <bump texture value>
 //   <environment|background r g b value texture> with nested texture transforms, <light type="point"> with
 //       <intensity>, <position>, <size>, <attenuation>, and <camera gamma="sRGB"> with position/target/up/fov/
-//       focaldist/dof/width/height
+//       focaldist/dof/width/height and <keyframe time> children (position/target/fov) for Camera::EvaluateAtTime
 // A colour is (r, g, b) (default 1) times `value` (default 1). Texture files are resolved by a caller-supplied
 // function (image decoders are outside the path); binary PPM (P6) and PFM (PF) are read directly.
 #pragma once
@@ -544,13 +544,23 @@ private:
             else if (c.name == "width") cam.imgWidth = (int)c.Float("value", (float)cam.imgWidth);
             else if (c.name == "height") cam.imgHeight = (int)c.Float("value", (float)cam.imgHeight);
         }
-        cam.pos = pos;
-        const Vec3f d = target - pos;
-        if (!haveFocal) cam.focaldist = d.Length();
-        cam.dir = d.GetNormalized();
-        const Vec3f x = cam.dir ^ up;
-        cam.up = (x ^ cam.dir).GetNormalized();
+        cam.upHint = up;
+        cam.LookAt(pos, target, haveFocal);
         cam.sRGB = e.Str("gamma") == "sRGB";
+        // <keyframe time="..."> position / target / fov </keyframe> (cerealBar.xml:220-271); missing fields keep the
+        // static camera's values
+        for (auto const& c : e.children) {
+            if (c.name != "keyframe") continue;
+            Camera::Keyframe k{(double)c.Float("time", 0.0f), pos, target, cam.fov};
+            for (auto const& f : c.children) {
+                if (f.name == "position") k.pos = Vec3f(f.Float("x", 0), f.Float("y", 0), f.Float("z", 0));
+                else if (f.name == "target") k.target = Vec3f(f.Float("x", 0), f.Float("y", 0), f.Float("z", 0));
+                else if (f.name == "fov") k.fov = f.Float("value", k.fov);
+            }
+            cam.keyframes.push_back(k);
+        }
+        std::stable_sort(cam.keyframes.begin(), cam.keyframes.end(),
+                         [](Camera::Keyframe const& a, Camera::Keyframe const& b) { return a.time < b.time; });
     }
 };
 

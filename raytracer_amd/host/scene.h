@@ -242,6 +242,47 @@ struct Camera {
     float fov = 40.0f, focaldist = 1.0f, dof = 0.0f;
     int imgWidth = 200, imgHeight = 150;
     bool sRGB = false;
+
+    // Camera animation (assets/cerealBar.xml:220-271 <keyframe time> with position / target / fov; consumed by the frame
+    // loop of Main.cpp:381-401 through Camera::EvaluateAtTime). The framework's interpolation is not in the reference
+    // repository: piecewise linear in position, target and fov here, held constant outside the keyed range.
+    struct Keyframe {
+        double time;
+        Vec3f pos, target;
+        float fov;
+    };
+    std::vector<Keyframe> keyframes;   // sorted by time
+    Vec3f upHint{0, 1, 0};             // the <up> vector the orthonormal frame is rebuilt from
+    bool IsAnimated() const { return !keyframes.empty(); }
+    double GetAnimationStart() const { return keyframes.empty() ? 0.0 : keyframes.front().time; }
+    double GetAnimationEnd() const { return keyframes.empty() ? 0.0 : keyframes.back().time; }
+    void LookAt(Vec3f const& p, Vec3f const& target, bool keepFocalDist = true) {
+        pos = p;
+        const Vec3f d = target - p;
+        if (!keepFocalDist) focaldist = d.Length();
+        dir = d.GetNormalized();
+        const Vec3f x = dir ^ upHint;
+        up = (x ^ dir).GetNormalized();
+    }
+    void EvaluateAtTime(double t) {
+        if (keyframes.empty()) return;
+        if (t <= keyframes.front().time || keyframes.size() == 1) {
+            fov = keyframes.front().fov;
+            LookAt(keyframes.front().pos, keyframes.front().target);
+            return;
+        }
+        if (t >= keyframes.back().time) {
+            fov = keyframes.back().fov;
+            LookAt(keyframes.back().pos, keyframes.back().target);
+            return;
+        }
+        size_t k = 1;
+        while (keyframes[k].time < t) ++k;
+        const Keyframe &a = keyframes[k - 1], &b = keyframes[k];
+        const float w = (float)((t - a.time) / (b.time - a.time));
+        fov = a.fov + (b.fov - a.fov) * w;
+        LookAt(a.pos + (b.pos - a.pos) * w, a.target + (b.target - a.target) * w);
+    }
 };
 
 // RenderImage: the output arrays CastRays fills (RayCaster.cpp:1000-1012, 1183-1211), row-major y*W+x

@@ -8,6 +8,7 @@
 #include <random>
 #include <thread>
 #include "../../raytracer_amd/host/RayCaster.h"
+#include "../../raytracer_amd/host/Animation.h"
 #include "../../raytracer_amd/host/ShadeInfoAdapter.h"
 #include "../../raytracer_amd/host/Denoiser.h"
 #include "../../raytracer_amd/host/SceneLoader.h"
@@ -443,6 +444,40 @@ int main() {
     long total = 0;
     for (size_t i = 0; i < np; ++i) total += img3.GetSampleCount()[i];
     CHECK(total < (long)np * 1024, "cancelled render took fewer samples (%ld)", total);
+
+    // animation frame loop (Main.cpp:381-401): the camera moves along its keyframes, the scene stays on the GPU
+    {
+        Camera anim = cam;
+        anim.imgWidth = 64; anim.imgHeight = 40;
+        anim.upHint = Vec3f(0, 1, 0);
+        anim.keyframes = {{0.0, cam.pos, Vec3f(1.2f, 0.3f, 0), 35.0f}, {1.0, cam.pos + Vec3f(2.0f, 0.5f, -1.0f), Vec3f(1.2f, 0.3f, 0), 30.0f}};
+        RayCaster ra(&scene, &anim);
+        ra.sampling.minSamples = ra.sampling.maxSamples = 2;
+        RenderImage imgA;
+        SequenceOptions so;
+        so.frames = 3; so.fps = 2.0; so.start = 0.0; so.end = 1.0;
+        so.outDir = "/tmp/rtx_host_parity_seq";
+        std::vector<std::vector<Color>> frames;
+        std::vector<double> times;
+        const size_t scenesBefore = GpuSceneRegistry().size();
+        const int nDone = RenderSequence(ra, anim, imgA, nullptr, so, [&](int, double t, RenderImage& im, double) {
+            frames.emplace_back(im.GetLinearPixels(), im.GetLinearPixels() + (size_t)im.GetWidth() * im.GetHeight());
+            times.push_back(t);
+        });
+        CHECK(nDone == 3 && times.size() == 3 && times[0] == 0.0 && times[1] == 0.5 && times[2] == 1.0, "frame times of the sequence");
+        CHECK(GpuSceneRegistry().size() == scenesBefore, "the scene is not rebuilt between frames");
+        double d01 = 0, d12 = 0;
+        for (size_t i = 0; i < frames[0].size(); ++i) {
+            d01 += std::fabs(frames[0][i].r - frames[1][i].r);
+            d12 += std::fabs(frames[1][i].r - frames[2][i].r);
+        }
+        CHECK(d01 / frames[0].size() > 1e-3 && d12 / frames[0].size() > 1e-3, "the camera moves between frames");
+        const OutputNames on = FormatBaseNames(so.outDir, so.prefix, 2, 4);
+        CHECK(on.color == "/tmp/rtx_host_parity_seq/beauty/render_0002.png", "output naming: %s", on.color.c_str());
+        FILE* fp = std::fopen(on.color.c_str(), "rb");
+        CHECK(fp != nullptr, "frame 2 was written");
+        if (fp) std::fclose(fp);
+    }
 
     ReleaseGpuScenes();
     orc_scene_destroy(osc);

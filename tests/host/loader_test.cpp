@@ -68,8 +68,28 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 12; ++k) std::printf("%.9g%s", ls.scene.environment.map ? ls.scene.environment.map->itm.m[k] : 0.0f, k < 11 ? ", " : "");
     const Camera& c = ls.camera;
     std::printf("]}, \"camera\": {\"pos\": [%.9g, %.9g, %.9g], \"dir\": [%.9g, %.9g, %.9g], \"up\": [%.9g, %.9g, %.9g], \"fov\": %.9g, "
-                "\"focaldist\": %.9g, \"dof\": %.9g, \"width\": %d, \"height\": %d, \"srgb\": %s}, \"warnings\": %d}\n",
+                "\"focaldist\": %.9g, \"dof\": %.9g, \"width\": %d, \"height\": %d, \"srgb\": %s, \"keyframes\": [",
                 c.pos.x, c.pos.y, c.pos.z, c.dir.x, c.dir.y, c.dir.z, c.up.x, c.up.y, c.up.z, c.fov, c.focaldist, c.dof, c.imgWidth, c.imgHeight,
-                c.sRGB ? "true" : "false", (int)ls.warnings.size());
+                c.sRGB ? "true" : "false");
+    for (size_t i = 0; i < c.keyframes.size(); ++i)
+        std::printf("%s{\"time\": %.9g, \"pos\": [%.9g, %.9g, %.9g], \"target\": [%.9g, %.9g, %.9g], \"fov\": %.9g}", i ? ", " : "",
+                    c.keyframes[i].time, c.keyframes[i].pos.x, c.keyframes[i].pos.y, c.keyframes[i].pos.z, c.keyframes[i].target.x,
+                    c.keyframes[i].target.y, c.keyframes[i].target.z, c.keyframes[i].fov);
+    // Camera::EvaluateAtTime at the times given after the scene file ("--at t0 t1 ..."), as the frame loop would call it
+    std::printf("], \"evaluated\": [");
+    bool firstT = true;
+    for (int a = 2; a < argc; ++a) {
+        if (std::string(argv[a]) != "--at") continue;
+        Camera cam = c;
+        for (int b = a + 1; b < argc; ++b) {
+            cam.EvaluateAtTime(std::atof(argv[b]));
+            std::printf("%s{\"t\": %s, \"pos\": [%.9g, %.9g, %.9g], \"dir\": [%.9g, %.9g, %.9g], \"up\": [%.9g, %.9g, %.9g], \"fov\": %.9g}",
+                        firstT ? "" : ", ", argv[b], cam.pos.x, cam.pos.y, cam.pos.z, cam.dir.x, cam.dir.y, cam.dir.z, cam.up.x, cam.up.y, cam.up.z,
+                        cam.fov);
+            firstT = false;
+        }
+        break;
+    }
+    std::printf("]}, \"warnings\": %d}\n", (int)ls.warnings.size());
     return 0;
 }

@@ -158,3 +158,26 @@ def test_reference_scene_file(loader):
         assert name in by_name, name
         assert np.allclose(m["diffuse"], by_name[name].diffuse, atol=1e-6), name
         assert np.isclose(m["glossiness"], by_name[name].glossiness), name
+
+
+def test_camera_keyframes(loader, tmp_path):
+    """<keyframe time> children of <camera> (assets/cerealBar.xml:220-271 holds them commented out; same syntax here)
+    and Camera::EvaluateAtTime as the frame loop of Main.cpp:381-401 calls it: piecewise linear in position, target and
+    fov, constant outside the keyed range, frame rebuilt from the <up> hint."""
+    (tmp_path / "anim.xml").write_text("""<xml><scene/>
+      <camera>
+        <position x="0" y="0" z="5"/> <target x="0" y="0" z="0"/> <up x="0" y="1" z="0"/> <fov value="30"/>
+        <keyframe time="2.0"> <position x="4" y="0" z="0"/> <target x="0" y="0" z="0"/> <fov value="50"/> </keyframe>
+        <keyframe time="0.0"> <position x="0" y="0" z="4"/> <target x="0" y="0" z="0"/> <fov value="30.00"/> </keyframe>
+      </camera></xml>""")
+    rc, s = loader(tmp_path / "anim.xml", "--at", "-1", "0", "1", "2", "9")
+    assert rc == 0, s
+    kf = s["camera"]["keyframes"]
+    assert [k["time"] for k in kf] == [0.0, 2.0] and kf[1]["pos"] == [4, 0, 0] and kf[1]["fov"] == 50      # sorted by time
+    ev = s["camera"]["evaluated"]
+    assert ev[0]["pos"] == ev[1]["pos"] == [0, 0, 4] and ev[3]["pos"] == ev[4]["pos"] == [4, 0, 0]
+    mid = ev[2]
+    assert np.allclose(mid["pos"], [2, 0, 2]) and mid["fov"] == pytest.approx(40.0)
+    assert np.allclose(mid["dir"], np.array([-1, 0, -1]) / np.sqrt(2), atol=1e-6)
+    assert np.allclose(mid["up"], [0, 1, 0], atol=1e-6)
+    assert s["camera"]["pos"] == [0, 0, 5]                        # the static camera is untouched by loading keyframes
