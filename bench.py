@@ -3,7 +3,7 @@
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A step is one full 1920x1080 frame at 128 spp through the hot path (ray-gen, extend, shade, shadow, resolve,
+A step is one full 1920x1080 frame at 128 spp through the hot path (ray-gen, extend, shade, shadow,
 film), config C3 of BASELINE.json, on the synthetic stand-in for assets/cerealBar.xml (the real geometry is
 Git-LFS only; see raytracer_amd/synth.py). With N ranks the 16x16 buckets are dealt round-robin to the ranks, every
 rank traces its buckets into a full-frame film in its own HBM, and the films are reduced to rank 0 over RCCL

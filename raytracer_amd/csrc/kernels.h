@@ -65,10 +65,9 @@ void launch_tail(const DevScene& sc, const LaunchCfg& cfg, const DevCamera& cam,
                  const SegQ& qIn, const uint32_t* queueIn, uint32_t n, int bounce0, int maxBounces, unsigned long long seed, int sBase,
                  int S, const int* pixels, int hasMicrofacet, int usePhotons);
 void launch_shadow(const DevScene& sc, const LaunchCfg& cfg, const PathPool& pool, const SegQ& q, uint32_t n, int useTransmittance);
-void launch_resolve(const PathPool& pool, const SegQ& qIn, const uint32_t* queueIn, uint32_t n, int nLights, int usePhotons,
-                    hipStream_t stream);
 void launch_film(const PathPool& pool, const rtx_film& film, const int* pixels, uint32_t nPix, int S, int W, int H, int filterType,
-                 float filterRadius, int resetZ, float4* samplesOut, int sBase, int sppTotal, float radianceClamp, hipStream_t stream);
+                 float filterRadius, int resetZ, float4* samplesOut, int sBase, int sppTotal, float radianceClamp, int nLights,
+                 int usePhotons, hipStream_t stream);
 // legacy shading mode (kernels_legacy.hip): TraceLegacy for the n camera samples whose primary hits are in pool.hits
 void launch_legacy(const DevScene& sc, const LaunchCfg& cfg, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pmGlobal,
                    const DevPhotonMap& pmCaustic, const SegQ& qIn, const uint32_t* queueIn, uint32_t n, unsigned long long seed,

@@ -102,6 +102,7 @@ __global__ void raygen_kernel(DevCamera cam, PathPool pool, const int* __restric
             pool.L[slot] = make_float4(0.0f, 0.0f, 0.0f, RTX_BIG);
             pool.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
             pool.medium[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(PF_LAST_DELTA));
+            pool.pendBeta[slot] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);   // nothing to resolve yet (resolve_add)
             pool.albedo[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             pool.normal[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             pool.samplePos[slot] = make_float2(samplePosX, samplePosY);
@@ -239,17 +240,6 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene sc, PathPoo
     atomicAdd(&pool.rayCounters[0], (unsigned long long)hops);
 }
 
-// ---- resolve: L += beta * sum_i c_i T_i  and the caustic term (RayCaster.cpp:470-522) ------------------------
-__global__ void resolve_kernel(PathPool pool, SegQ qIn, const uint32_t* __restrict__ queueIn, uint32_t n, int nLights, int usePhotons) {
-    __shared__ uint32_t qtab[SEGQ_TABLE_WORDS];
-    segq_load_table(qIn, qtab);
-    __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t slot = queueIn[segq_item_index(qtab, i)];
-    resolve_slot(pool, slot, nLights, usePhotons);
-}
-
 // ---- film (RayCaster.cpp:798-838) -----------------------------------------------------------------------------
 __device__ __forceinline__ float filter_radius(int type, float radiusOverride) {   // :84-92, :807
     if (radiusOverride > 0.0f) return radiusOverride;
@@ -303,7 +293,7 @@ __device__ __forceinline__ float filter1d(int type, float radius, float x) {   /
 template <bool NEAR3>
 __global__ void film_kernel(PathPool pool, rtx_film film, const int* __restrict__ pixels, uint32_t nPix, int S, int W, int H,
                             int filterType, float filterRadius, int resetZ, float4* __restrict__ samplesOut, int sBase,
-                            int sppTotal, float radianceClamp) {
+                            int sppTotal, float radianceClamp, int nLights, int usePhotons) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nPix) return;
     const int pix = pixels[i];
@@ -327,7 +317,12 @@ __global__ void film_kernel(PathPool pool, rtx_film film, const int* __restrict_
     }
     for (int s = 0; s < S; ++s) {
         const uint32_t slot = (chunk * (uint32_t)S + (uint32_t)s) * 64u + lane;
-        const float4 L4 = pool.L[slot];
+        float4 L4 = pool.L[slot];
+        {   // a path that ended in the bounce loop still owes the NEE of its last vertex (resolve_add)
+            f3 Lr = mk3(L4.x, L4.y, L4.z);
+            resolve_add(pool, slot, nLights, usePhotons != 0, Lr);
+            L4.x = Lr.x; L4.y = Lr.y; L4.z = Lr.z;
+        }
         // kRadianceClamp (RayCaster.cpp:569-571) in path mode; TraceLegacy returns its radiance unclamped
         const float cr = fminf(L4.x, radianceClamp), cg = fminf(L4.y, radianceClamp), cb = fminf(L4.z, radianceClamp);
         if (samplesOut) samplesOut[(size_t)pix * sppTotal + sBase + s] = make_float4(cr, cg, cb, L4.w);
@@ -525,21 +520,17 @@ void launch_shadow(const DevScene& sc, const LaunchCfg& cfg, const PathPool& poo
     hipLaunchKernelGGL(shadow_kernel, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, pool, q, useTransmittance, cfg.spill,
                        segq_chunk(n, grid * (TRAV_BLOCK / 64)));
 }
-void launch_resolve(const PathPool& pool, const SegQ& qIn, const uint32_t* queueIn, uint32_t n, int nLights, int usePhotons,
-                    hipStream_t stream) {
-    if (!n) return;
-    hipLaunchKernelGGL(resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pool, qIn, queueIn, n, nLights, usePhotons);
-}
 void launch_film(const PathPool& pool, const rtx_film& film, const int* pixels, uint32_t nPix, int S, int W, int H, int filterType,
-                 float filterRadius, int resetZ, float4* samplesOut, int sBase, int sppTotal, float radianceClamp, hipStream_t stream) {
+                 float filterRadius, int resetZ, float4* samplesOut, int sBase, int sppTotal, float radianceClamp, int nLights,
+                 int usePhotons, hipStream_t stream) {
     if (!nPix) return;
     const bool near3 = filterType == RTX_FILTER_TENT && (filterRadius <= 0.0f || filterRadius <= 1.0f);
     if (near3)
         hipLaunchKernelGGL(film_kernel<true>, dim3((nPix + 255) / 256), dim3(256), 0, stream, pool, film, pixels, nPix, S, W, H,
-                           filterType, filterRadius, resetZ, samplesOut, sBase, sppTotal, radianceClamp);
+                           filterType, filterRadius, resetZ, samplesOut, sBase, sppTotal, radianceClamp, nLights, usePhotons);
     else
         hipLaunchKernelGGL(film_kernel<false>, dim3((nPix + 255) / 256), dim3(256), 0, stream, pool, film, pixels, nPix, S, W, H,
-                           filterType, filterRadius, resetZ, samplesOut, sBase, sppTotal, radianceClamp);
+                           filterType, filterRadius, resetZ, samplesOut, sBase, sppTotal, radianceClamp, nLights, usePhotons);
 }
 void launch_adaptive(const PathPool& pool, const int* pixels, uint32_t nPix, float maxHalf, int sppMax, int* pixelsNext,
                      uint32_t* counter, hipStream_t stream) {

@@ -10,8 +10,8 @@
 // the latency that counts: lane 0 traces the next ray of the path while lanes 1..3 trace the shadow chains of the
 // vertex just shaded (rounds of four jobs when the scene has more than three lights). Every job is a chain of
 // closest hits through one loop - the extend job is a chain that ends after its first hop - so the four lanes stay in
-// one instruction stream. Results go round the quad by shuffles; each lane then writes the transmittances and runs
-// the same resolve as resolve_kernel, so a lane only ever reads what it has written itself.
+// one instruction stream. Results go round the quad by shuffles; each lane then writes the transmittances and resolves
+// the vertex (resolve_slot), so a lane only ever reads what it has written itself.
 template <bool MICRO>
 __global__ __launch_bounds__(TRAV_BLOCK) void tail_kernel(DevScene sc, DevCamera cam, PathPool pool, DevPhotonMap pm, SegQ qIn,
                                                           const uint32_t* __restrict__ queueIn, uint32_t n, int bounce0, int maxBounces,
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void tail_kernel(DevScene sc, DevCamera
                 if (jk >= 1 && ak) pool.nee[(size_t)(jk - 1) * cap + slot].w = Tk;
             }
         }
-        if (haveVertex) resolve_slot(pool, slot, nL, usePhotons);
+        if (haveVertex) resolve_slot(pool, slot, nL, usePhotons != 0);
         haveVertex = false;
         if (needExtend) {
             needExtend = shade_body<MICRO, true>(sc, cam, pool, pm, slot, ray, hit, bounce, maxBounces, seed, sBase, S, pixels, SegQ{nullptr});

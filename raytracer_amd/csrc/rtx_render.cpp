@@ -19,7 +19,7 @@ struct PathPoolHost {
     bool hasCaustic = false;
     std::vector<hipEvent_t> events;
     size_t bytes = 0;
-    // second stream: the shadow + resolve kernels of bounce k run beside the extend kernel of bounce k+1
+    // second stream: the shadow kernel of bounce k runs beside the extend kernel of bounce k+1
     hipStream_t sideStream = nullptr;
     hipEvent_t sideDone = nullptr;
     uint2* sideSpill = nullptr;   // its own traversal spill slab (both kernels are in flight at once)
@@ -371,7 +371,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 RTX_HIP(hipMemcpyAsync(cnt, pool.totals, sizeof(cnt), hipMemcpyDeviceToHost, st));
                 RTX_HIP(hipStreamSynchronize(st));
                 // the host has synchronised the main stream: what goes to the side stream now runs after shade(k)
-                const bool side = overlap && cnt[0] > 0 && cnt[0] <= overlapMax;   // cnt[0] = 0: nothing to overlap with
+                const bool side = overlap && cnt[1] > 0 && cnt[0] > 0 && cnt[0] <= overlapMax;   // cnt[0] = 0: nothing to overlap with
                 hipStream_t sst = side ? ph->sideStream : st;
                 if (cnt[1]) {
                     tm.nextItems = cnt[1];
@@ -379,7 +379,6 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                     launch_shadow(s->dev, side ? sideCfg : s->cfg, pool, pool.qS, cnt[1], bounce <= 8 ? 1 : 0);   // useTransmittance (RayCaster.cpp:454)
                     tm.end(sst);
                 }
-                launch_resolve(pool, sqIn, qin, n, s->dev.n_lights, usePhotons ? 1 : 0, sst);
                 if (side) {
                     RTX_HIP(hipEventRecord(ph->sideDone, ph->sideStream));
                     sidePending = true;
@@ -396,7 +395,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                     tm.nextItems = n;
                     tm.begin(2, st);
                     launch_tail(s->dev, s->cfg, dc, pool, pm, sqIn, qin, n, bounce + 1, rp->max_bounces, rp->seed, sBase, Sp, curPixels,
-                                s->hasMicrofacet, usePhotons ? 1 : 0);
+                                s->hasMicrofacet, pm.n > 0 ? 1 : 0);
                     tm.end(st);
                     n = 0;
                 }
@@ -414,7 +413,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
             if (!s->cancel.load(std::memory_order_relaxed))
                 launch_film(pool, *film, curPixels, nPix, Sp, W, H, rp->filter_type, rp->filter_radius,
                             (done == 0 && (spec ? spec->resetZ != 0 : round == 1)) ? 1 : 0, samplesOut, sBase, sppMax,
-                            legacy ? 3.0e38f : 10.0f, st);
+                            legacy ? 3.0e38f : 10.0f, s->dev.n_lights, pm.n > 0 ? 1 : 0, st);
             done += Sp;
         }
         roundBase += target;

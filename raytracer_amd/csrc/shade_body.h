@@ -46,7 +46,44 @@ __device__ __forceinline__ bool has_map_or_value(const float* c, int tex) {   //
 
 
 // One bounce of TracePath (RayCaster.cpp:359-567) for every path in queueIn. Paths that continue are appended to
-// queueOut; NEE shadow segments are appended to the shadow queue; their results are folded in by resolve_kernel.
+// queueOut; NEE shadow segments are appended to the shadow queue; their results are folded in by resolve_add.
+// L += beta * sum_i c_i T_i and the caustic term of one path vertex once its shadow results are in pool.nee[].w
+// (RayCaster.cpp:470-522), in the reference's order of additions into L. There is no resolve launch: the additions of
+// bounce k are made by whoever reads the path's L next - the shading of bounce k+1 (they come before that vertex's own
+// terms, as in the reference), the tail kernel, or the film kernel for a path that ended at bounce k.
+// Returns false when nothing is pending (pendBeta.w < 0).
+__device__ __forceinline__ bool resolve_add(const PathPool& pool, uint32_t slot, int nLights, bool usePhotons, f3& L) {
+    const float4 pb = pool.pendBeta[slot];
+    if (pb.w < 0.0f) return false;
+    const f3 beta = mk3(pb.x, pb.y, pb.z);
+    f3 direct = mk3(0.0f);
+    float maxVisibility = 0.0f;
+    for (int l = 0; l < nLights; ++l) {
+        const float4 c = pool.nee[(size_t)l * pool.capacity + slot];
+        if (c.w < 0.0f) continue;
+        maxVisibility = fmaxf(maxVisibility, c.w);
+        if (c.w <= 0.0f) continue;
+        direct = direct + mk3(c.x, c.y, c.z) * c.w;
+    }
+    if (max3c(direct) > 0.0f) L = L + beta * direct;
+    if (usePhotons) {
+        const float4 cz = pool.caustic[slot];
+        if (cz.w > 0.0f) {
+            const float causticScale = 0.1f + 0.9f * maxVisibility;
+            L = L + beta * (mk3(cz.x, cz.y, cz.z) * causticScale);
+        }
+    }
+    return true;
+}
+// the same, written back (tail kernel: the vertex is resolved as soon as its shadow chains are traced)
+__device__ __forceinline__ void resolve_slot(const PathPool& pool, uint32_t slot, int nLights, bool usePhotons) {
+    float4 L4 = pool.L[slot];
+    f3 L = mk3(L4.x, L4.y, L4.z);
+    if (!resolve_add(pool, slot, nLights, usePhotons, L)) return;
+    pool.L[slot] = make_float4(L.x, L.y, L.z, L4.w);
+    pool.pendBeta[slot] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+}
+
 // One vertex of one path: returns true when the path continues (its next ray is in pool.rays[slot]).
 // MICRO: the scene holds MtlMicrofacet materials (a second BSDF in the kernel; scenes without them run the leaner one).
 // TAIL: the caller is tail_kernel, which walks a path to its end inside one kernel: the shadow segment of light l goes
@@ -64,6 +101,7 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
         float4 b4 = pool.beta[slot];
         float4 m4 = pool.medium[slot];
         f3 L = mk3(L4.x, L4.y, L4.z);
+        resolve_add(pool, slot, sc.n_lights, pm.n > 0, L);   // the NEE of the previous vertex (its shadow results are in)
         f3 beta = mk3(b4.x, b4.y, b4.z);
         float lastPdf = b4.w;
         uint32_t flags = __float_as_uint(m4.w);
@@ -205,7 +243,7 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
             }
             if (pending) pool.pendBeta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
 
-            if (pm.n > 0) {   // :508-522 (scaled by the visibility in resolve_kernel)
+            if (pm.n > 0) {   // :508-522 (scaled by the visibility in resolve_add)
                 float4 cz = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (photonSurface) {
                     f3 irrad = estimate_irradiance(pm, sh.p, sh.N);
@@ -259,37 +297,9 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
         pool.beta[slot] = make_float4(beta.x, beta.y, beta.z, lastPdf);
         pool.medium[slot] = make_float4(mediumAbs.x, mediumAbs.y, mediumAbs.z, __uint_as_float(flags));
         if (!pending) {
-            // mark "nothing to resolve" for resolve_kernel
+            // mark "nothing to resolve" for resolve_add
             pool.pendBeta[slot] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
         }
     }
     return alive;
-}
-
-// L += beta * sum_i c_i T_i and the caustic term of one path vertex once its shadow results are in pool.nee[].w
-// (RayCaster.cpp:470-522), in the reference's order of additions into L.
-__device__ __forceinline__ void resolve_slot(const PathPool& pool, uint32_t slot, int nLights, int usePhotons) {
-    const float4 pb = pool.pendBeta[slot];
-    if (pb.w < 0.0f) return;
-    const f3 beta = mk3(pb.x, pb.y, pb.z);
-    float4 L4 = pool.L[slot];
-    f3 L = mk3(L4.x, L4.y, L4.z);
-    f3 direct = mk3(0.0f);
-    float maxVisibility = 0.0f;
-    for (int l = 0; l < nLights; ++l) {
-        const float4 c = pool.nee[(size_t)l * pool.capacity + slot];
-        if (c.w < 0.0f) continue;
-        maxVisibility = fmaxf(maxVisibility, c.w);
-        if (c.w <= 0.0f) continue;
-        direct = direct + mk3(c.x, c.y, c.z) * c.w;
-    }
-    if (max3c(direct) > 0.0f) L = L + beta * direct;
-    if (usePhotons) {
-        const float4 cz = pool.caustic[slot];
-        if (cz.w > 0.0f) {
-            const float causticScale = 0.1f + 0.9f * maxVisibility;
-            L = L + beta * (mk3(cz.x, cz.y, cz.z) * causticScale);
-        }
-    }
-    pool.L[slot] = make_float4(L.x, L.y, L.z, L4.w);
 }
