@@ -100,8 +100,8 @@ def main():
     ra.film_clear(film, W, H)
     stc = scene.render_accumulate(cam, rp_c, film)
     scene.set_counters(False)
-    # rays traced by extend_kernel launches (legacy mode: the primary rays; its secondary rays run inside legacy_kernel)
-    ext_rays_c = stc["rays_primary"] + (0 if a.legacy else stc["rays_bounce"])
+    # rays traced by extend_kernel launches (not those of the tail / legacy kernels, which extend_ms does not time)
+    ext_rays_c = stc["rays_extend"]
     nodes_per_ray = stc["nodes_visited"] / max(1, ext_rays_c)
     tris_per_ray = stc["tris_tested"] / max(1, ext_rays_c)
     bytes_per_ray = 32 + 16 + nodes_per_ray * info["node_bytes"] + tris_per_ray * info["tri_bytes"]
@@ -114,7 +114,7 @@ def main():
     for _ in range(a.steps):
         st = step()
         agg["rays"] += st["rays_primary"] + st["rays_bounce"] + st["rays_shadow"]
-        agg["ext_rays"] += st["rays_primary"] + (0 if a.legacy else st["rays_bounce"])
+        agg["ext_rays"] += st["rays_extend"]
         agg["shadow_rays"] += st["rays_shadow"]
         agg["extend_ms"] += st["extend_ms"]
         agg["shadow_ms"] += st["shadow_ms"]

@@ -206,6 +206,8 @@ typedef struct {
     double   shade_ms;
     double   total_ms;
     uint64_t extend_launches;
+    uint64_t rays_extend;          /* primary + bounce rays traced by the extend launches that extend_ms times
+                                    * (bounce rays of the tail / legacy kernels are in rays_bounce only)       */
 } rtx_stats;
 
 /* Photon mapping (PhotonMapBuilder.h:46-54). */

@@ -100,7 +100,8 @@ class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_bounce", C.c_uint64), ("rays_shadow", C.c_uint64),
                 ("rays_photon", C.c_uint64), ("paths", C.c_uint64), ("nodes_visited", C.c_uint64),
                 ("tris_tested", C.c_uint64), ("extend_ms", C.c_double), ("shadow_ms", C.c_double),
-                ("shade_ms", C.c_double), ("total_ms", C.c_double), ("extend_launches", C.c_uint64)]
+                ("shade_ms", C.c_double), ("total_ms", C.c_double), ("extend_launches", C.c_uint64),
+                ("rays_extend", C.c_uint64)]
 
 
 class PhotonParams(C.Structure):

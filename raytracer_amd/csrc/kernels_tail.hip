@@ -12,28 +12,52 @@
 // closest hits through one loop - the extend job is a chain that ends after its first hop - so the four lanes stay in
 // one instruction stream. Results go round the quad by shuffles; each lane then writes the transmittances and resolves
 // the vertex (resolve_slot), so a lane only ever reads what it has written itself.
+#ifndef TAIL_REFILL_MIN
+#define TAIL_REFILL_MIN 2u   // idle quads of a wave before it fetches new paths
+#endif
 template <bool MICRO>
 __global__ __launch_bounds__(TRAV_BLOCK) void tail_kernel(DevScene sc, DevCamera cam, PathPool pool, DevPhotonMap pm, SegQ qIn,
-                                                          const uint32_t* __restrict__ queueIn, uint32_t n, int bounce0, int maxBounces,
+                                                          const uint32_t* __restrict__ queueIn, int bounce0, int maxBounces,
                                                           unsigned long long seed, int sBase, int S, const int* __restrict__ pixels,
-                                                          int usePhotons, uint2* spill) {
-    __shared__ uint32_t qtab[SEGQ_TABLE_WORDS];
+                                                          int usePhotons, uint2* spill, uint32_t chunk) {
     __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
-    segq_load_table(qIn, qtab);
-    __syncthreads();
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t q = gtid & 3u, path = gtid >> 2;
-    const int quadBase = (int)(threadIdx.x & 63u & ~3u);
+    const uint32_t lane = threadIdx.x & 63u, q = lane & 3u;
+    const int quadBase = (int)(lane & ~3u);
     TravStack st{&lds_stack[threadIdx.x], spill + gtid, gridDim.x * blockDim.x};
     const int nL = sc.n_lights;
     const uint32_t cap = pool.capacity, mult = (uint32_t)max(1, nL);
     uint32_t hops = 0, rays = 0;
-    const bool valid = path < n;
-    const uint32_t slot = valid ? queueIn[segq_item_index(qtab, path)] : 0u;
-    bool needExtend = valid;    // the path's next ray waits in pool.rays[slot]
+    // persistent grid: the 16 quads of a wave take paths from the queue as they become free (segqueue.h)
+    SegWalk walk;
+    segq_walk_init(qIn, walk, gtid >> 6, chunk);
+    bool exhausted = false;
+    uint32_t slot = 0u;
+    bool needExtend = false;    // the path's next ray waits in pool.rays[slot]
     bool haveVertex = false;    // the NEE of the vertex shaded last waits for its shadow results
     int bounce = bounce0;       // bounce index of that next ray
-    while (needExtend || haveVertex) {
+    for (;;) {
+        const bool busy = needExtend || haveVertex;   // the same in the four lanes of a quad
+        const unsigned long long idleQuads = __ballot(!busy && q == 0u);
+        const uint32_t nIdle = (uint32_t)__popcll(idleQuads);
+        if (!exhausted && (nIdle >= TAIL_REFILL_MIN || __ballot(busy) == 0ull)) {
+            uint32_t first = 0;
+            const uint32_t got = segq_take(qIn, walk, nIdle, first);
+            if (got == 0u) exhausted = true;
+            const uint32_t rank = (uint32_t)__popcll(idleQuads & ((1ull << quadBase) - 1ull));   // idle quads below this one
+            if (!busy && rank < got) {
+                slot = queueIn[first + rank];
+                needExtend = true;
+                haveVertex = false;
+                bounce = bounce0;
+            }
+        }
+        if (__ballot(needExtend || haveVertex) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        if (!(needExtend || haveVertex)) continue;
+        // ---- one step of this quad's path: trace (next ray + shadows of the last vertex), resolve, shade ----
         RayT ray{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f};
         if (needExtend) {
             const float4 ra = pool.rays[2 * (size_t)slot], rb = pool.rays[2 * (size_t)slot + 1];
@@ -106,7 +130,6 @@ __global__ __launch_bounds__(TRAV_BLOCK) void tail_kernel(DevScene sc, DevCamera
             ++bounce;
         }
     }
-    if (q != 0u) rays = 0;   // hops are counted by the lane that traced them, the path's rays by lane 0
     atomicAdd(&pool.rayCounters[0], (unsigned long long)hops);
     atomicAdd(&pool.rayCounters[1], (unsigned long long)rays);
 }
@@ -115,11 +138,15 @@ void launch_tail(const DevScene& sc, const LaunchCfg& cfg, const DevCamera& cam,
                  const SegQ& qIn, const uint32_t* queueIn, uint32_t n, int bounce0, int maxBounces, unsigned long long seed, int sBase,
                  int S, const int* pixels, int hasMicrofacet, int usePhotons) {
     if (!n) return;
-    const uint32_t grid = (4u * n + TRAV_BLOCK - 1) / TRAV_BLOCK;   // 4 lanes per path; 4n <= gridBlocks * TRAV_BLOCK: inside the spill slab
+    const uint32_t need = (4u * n + TRAV_BLOCK - 1) / TRAV_BLOCK;   // 4 lanes per path
+    const uint32_t grid = need < (uint32_t)cfg.gridBlocks ? need : (uint32_t)cfg.gridBlocks;   // the spill slab covers gridBlocks blocks
+    // paths reserved per atomic by a wave of 16 quads: small enough that every wave of the grid gets some
+    uint32_t chunk = n / (grid * (TRAV_BLOCK / 64u) * 2u);
+    chunk = chunk < 16u ? 16u : (chunk > 256u ? 256u : (chunk / 16u) * 16u);
     if (hasMicrofacet)
-        hipLaunchKernelGGL(tail_kernel<true>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, cam, pool, pm, qIn, queueIn, n, bounce0,
-                           maxBounces, seed, sBase, S, pixels, usePhotons, cfg.spill);
+        hipLaunchKernelGGL(tail_kernel<true>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, cam, pool, pm, qIn, queueIn, bounce0,
+                           maxBounces, seed, sBase, S, pixels, usePhotons, cfg.spill, chunk);
     else
-        hipLaunchKernelGGL(tail_kernel<false>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, cam, pool, pm, qIn, queueIn, n, bounce0,
-                           maxBounces, seed, sBase, S, pixels, usePhotons, cfg.spill);
+        hipLaunchKernelGGL(tail_kernel<false>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, cam, pool, pm, qIn, queueIn, bounce0,
+                           maxBounces, seed, sBase, S, pixels, usePhotons, cfg.spill, chunk);
 }

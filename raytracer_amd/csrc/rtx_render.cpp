@@ -295,7 +295,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     RTX_HIP(hipMemsetAsync(pool.qB.ctl, 0, SEGQ_WORDS * sizeof(uint32_t), st));
     RTX_HIP(hipMemsetAsync(pool.qS.ctl, 0, SEGQ_WORDS * sizeof(uint32_t), st));
     const uint32_t shadowMult = (uint32_t)std::max(1, s->dev.n_lights);
-    uint32_t tailMax = std::min<uint32_t>(RTX_TAIL_MAX_PATHS, (uint32_t)s->cfg.gridBlocks * TRAV_BLOCK / 4u);   // 4 lanes per path
+    uint32_t tailMax = RTX_TAIL_MAX_PATHS;
     if (const char* e = std::getenv("RTX_AMD_TAIL_PATHS")) tailMax = std::min<uint32_t>(tailMax, (uint32_t)std::atol(e));   // 0 disables
     if (s->cfg.counting) tailMax = 0;   // node / triangle tallies exist in the counting build of extend_kernel only
 
@@ -441,6 +441,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     unsigned long long rc2[2] = {0, 0};   // [0] shadow hops, [1] closest-hit rays traced inside tail_kernel
     RTX_HIP(hipMemcpy(rc2, pool.rayCounters, sizeof(rc2), hipMemcpyDeviceToHost));
     out.rays_shadow = rc2[0];
+    out.rays_extend = out.rays_primary + out.rays_bounce;   // traced by extend launches (the rest: tail / legacy kernel)
     out.rays_bounce += rc2[1];
     out.extend_ms = tm.ms[0];
     out.shadow_ms = tm.ms[1];
