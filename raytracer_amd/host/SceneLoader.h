@@ -12,7 +12,8 @@
 //       <intensity>, <position>, <size>, <attenuation>, and <camera gamma="sRGB"> with position/target/up/fov/
 //       focaldist/dof/width/height and <keyframe time> children (position/target/fov) for Camera::EvaluateAtTime
 // A colour is (r, g, b) (default 1) times `value` (default 1). Texture files are resolved by a caller-supplied
-// function (image decoders are outside the path); binary PPM (P6) and PFM (PF) are read directly.
+// function first; binary PPM (P6), PFM (PF), PNG and Radiance HDR (ImageDecode.h: the two formats the reference's
+// scene file names) are read directly.
 #pragma once
 #include <cctype>
 #include <cmath>
@@ -24,6 +25,7 @@
 #include <map>
 #include <sstream>
 #include "scene.h"
+#include "ImageDecode.h"
 
 namespace rtamd {
 
@@ -426,6 +428,8 @@ private:
         std::shared_ptr<TextureMap> t;
         if (textureResolver) t = textureResolver(baseDir + name);
         if (!t) t = LoadPnm(baseDir + name);
+        if (!t) t = imgdec::LoadPng(baseDir + name);
+        if (!t) t = imgdec::LoadHdr(baseDir + name);
         if (!t) ls->warnings.push_back("texture not loaded: " + name);
         textures[name] = t;
         return t;

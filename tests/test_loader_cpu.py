@@ -181,3 +181,170 @@ def test_camera_keyframes(loader, tmp_path):
     assert np.allclose(mid["dir"], np.array([-1, 0, -1]) / np.sqrt(2), atol=1e-6)
     assert np.allclose(mid["up"], [0, 1, 0], atol=1e-6)
     assert s["camera"]["pos"] == [0, 0, 5]                        # the static camera is untouched by loading keyframes
+
+
+@pytest.fixture(scope="module")
+def image_decoder(tmp_path_factory):
+    d = tmp_path_factory.mktemp("imgdec")
+    exe = d / "image_test"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", str(exe), os.path.join(ROOT, "tests", "host", "image_test.cpp")])
+
+    def run(path):
+        raw = d / "out.raw"
+        r = subprocess.run([str(exe), str(path), str(raw)], capture_output=True, text=True)
+        info = json.loads(r.stdout)
+        if r.returncode != 0:
+            return info, None
+        a = np.fromfile(raw, np.float32 if info["float"] else np.uint8).reshape(info["h"], info["w"], 3)
+        return info, a
+    return run
+
+
+def _png_bytes(rows, w, h, depth, ctype, filters, level=9, strategy=0, palette=None):
+    """A PNG file from raw scanline bytes, with the given filter type per row (PNG specification, section 9)."""
+    import struct
+    import zlib
+    bpp = max(1, {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype] * depth // 8)
+    out = bytearray()
+    prev = np.zeros(len(rows[0]), np.int32)
+    for y, row in enumerate(rows):
+        cur = np.frombuffer(bytes(row), np.uint8).astype(np.int32)
+        a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+        c = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+        ft = filters[y % len(filters)]
+        if ft == 0: pred = 0
+        elif ft == 1: pred = a
+        elif ft == 2: pred = prev
+        elif ft == 3: pred = (a + prev) // 2
+        else:
+            p = a + prev - c
+            pa, pb, pc = abs(p - a), abs(p - prev), abs(p - c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+        out.append(ft)
+        out += ((cur - pred) & 255).astype(np.uint8).tobytes()
+        prev = cur
+    co = zlib.compressobj(level, zlib.DEFLATED, 15, 9, strategy)
+    z = co.compress(bytes(out)) + co.flush()
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    f = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+    if palette is not None:
+        f += chunk(b"PLTE", bytes(palette))
+    half = len(z) // 2                                   # two IDAT chunks: the stream continues across them
+    return f + chunk(b"IDAT", z[:half]) + chunk(b"IDAT", z[half:]) + chunk(b"IEND", b"")
+
+
+def test_png_decoder(image_decoder, tmp_path):
+    """host/ImageDecode.h LoadPng: every colour type / bit depth the decoder accepts, the five scanline filters, stored /
+    fixed / dynamic Huffman blocks, split IDAT chunks."""
+    import zlib
+    rng = np.random.default_rng(3)
+    w, h = 37, 23
+    smooth = (np.add.outer(np.arange(h) * 5, np.arange(w) * 3)[..., None] + np.array([0, 40, 90])) % 256
+    img = np.where(rng.random((h, w, 1)) < 0.3, rng.integers(0, 256, (h, w, 3)), smooth).astype(np.uint8)
+    cases = [("rgb8", 8, 2, [row.tobytes() for row in img], img)]
+    rgba = np.concatenate([img, rng.integers(0, 256, (h, w, 1), dtype=np.uint8)], 2)
+    cases.append(("rgba8", 8, 6, [row.tobytes() for row in rgba], img))
+    grey = img[..., :1]
+    cases.append(("grey8", 8, 0, [row.tobytes() for row in grey], np.repeat(grey, 3, 2)))
+    ga = np.concatenate([grey, rgba[..., 3:]], 2)
+    cases.append(("greyalpha8", 8, 4, [row.tobytes() for row in ga], np.repeat(grey, 3, 2)))
+    hi = img.astype(np.uint16) * 256 + rng.integers(0, 256, img.shape).astype(np.uint16)
+    cases.append(("rgb16", 16, 2, [row.astype(">u2").tobytes() for row in hi], img))
+    for name, depth, ctype, rows, expect in cases:
+        for level, strategy in ((9, 0), (0, 0), (6, zlib.Z_FIXED)):
+            p = tmp_path / f"{name}_{level}_{strategy}.png"
+            p.write_bytes(_png_bytes(rows, w, h, depth, ctype, [0, 1, 2, 3, 4], level, strategy))
+            info, a = image_decoder(p)
+            assert a is not None and (info["w"], info["h"], info["float"]) == (w, h, False), (name, info)
+            assert np.array_equal(a, expect), (name, level, strategy)
+    # palette, 8 and 4 bits per index; 1-bit grey
+    pal = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    idx = rng.integers(0, 16, (h, w), dtype=np.uint8)
+    p = tmp_path / "pal8.png"
+    p.write_bytes(_png_bytes([row.tobytes() for row in idx], w, h, 8, 3, [0, 2], palette=pal.tobytes()))
+    assert np.array_equal(image_decoder(p)[1], pal[idx])
+    packed = [np.packbits(np.unpackbits(row[:, None], axis=1)[:, 4:].ravel()).tobytes() for row in idx]
+    p = tmp_path / "pal4.png"
+    p.write_bytes(_png_bytes(packed, w, h, 4, 3, [0, 1], palette=pal.tobytes()))
+    assert np.array_equal(image_decoder(p)[1], pal[idx])
+    bits = rng.integers(0, 2, (h, w), dtype=np.uint8)
+    p = tmp_path / "grey1.png"
+    p.write_bytes(_png_bytes([np.packbits(row).tobytes() for row in bits], w, h, 1, 0, [0]))
+    assert np.array_equal(image_decoder(p)[1], np.repeat((bits * 255)[..., None], 3, 2))
+    # not a PNG, truncated stream: refused, not crashed
+    (tmp_path / "bad.png").write_bytes(b"\x89PNG\r\n\x1a\n" + b"\0" * 40)
+    assert image_decoder(tmp_path / "bad.png")[1] is None
+    good = _png_bytes(cases[0][3], w, h, 8, 2, [4])
+    (tmp_path / "cut.png").write_bytes(good[:len(good) // 2])
+    assert image_decoder(tmp_path / "cut.png")[1] is None
+
+
+def _rgbe_to_float(rgbe):
+    e = rgbe[..., 3].astype(np.int32)
+    f = np.ldexp(np.float32(1.0), e - 136).astype(np.float32)
+    out = rgbe[..., :3].astype(np.float32) * f[..., None]
+    out[e == 0] = 0
+    return out
+
+
+def test_radiance_hdr_decoder(image_decoder, tmp_path):
+    """host/ImageDecode.h LoadHdr: flat and run-length encoded scanlines against a numpy RGBE conversion."""
+    rng = np.random.default_rng(9)
+    w, h = 40, 9
+    rgbe = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    rgbe[..., 3] = rng.integers(100, 150, (h, w))
+    rgbe[2, 5:30] = rgbe[2, 5]                               # a long run
+    rgbe[4, :, 3] = 0                                          # zero exponent = black
+    header = b"#?RADIANCE\n# made by a test\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w)
+    (tmp_path / "flat.hdr").write_bytes(header + rgbe.tobytes())
+    info, a = image_decoder(tmp_path / "flat.hdr")
+    assert (info["w"], info["h"], info["float"]) == (w, h, True) and np.array_equal(a, _rgbe_to_float(rgbe))
+
+    def rle(row):                                              # new-style RLE of one scanline (runs >= 3 as runs)
+        out = bytearray([2, 2, w >> 8, w & 255])
+        for ch in range(4):
+            v = row[:, ch]
+            x = 0
+            while x < w:
+                r = 1
+                while x + r < w and r < 127 and v[x + r] == v[x]:
+                    r += 1
+                if r >= 3:
+                    out += bytes([128 + r, v[x]])
+                    x += r
+                else:
+                    s = x
+                    while x < w and x - s < 128:
+                        r = 1
+                        while x + r < w and r < 3 and v[x + r] == v[x]:
+                            r += 1
+                        if r >= 3:
+                            break
+                        x += 1
+                    out += bytes([x - s]) + v[s:x].tobytes()
+        return bytes(out)
+    (tmp_path / "rle.hdr").write_bytes(header + b"".join(rle(row) for row in rgbe))
+    info, a = image_decoder(tmp_path / "rle.hdr")
+    assert a is not None and np.array_equal(a, _rgbe_to_float(rgbe))
+    (tmp_path / "cut.hdr").write_bytes((header + rgbe.tobytes())[:200])
+    assert image_decoder(tmp_path / "cut.hdr")[1] is None
+
+
+@pytest.mark.skipif(not os.path.exists(REF_XML), reason="the reference's texture files exist in the build container only")
+def test_reference_texture_files(image_decoder):
+    """The two textures the reference ships (assets/textures): bgPlate.png against PIL's decoder when PIL is there,
+    alps_field_1k.hdr (the environment of cerealBar.xml:180) by size and range."""
+    tex = os.path.join(os.path.dirname(REF_XML), "textures")
+    info, a = image_decoder(os.path.join(tex, "bgPlate.png"))
+    assert a is not None and not info["float"] and a.std() > 1
+    try:
+        from PIL import Image
+        ref = np.asarray(Image.open(os.path.join(tex, "bgPlate.png")).convert("RGB"))
+        assert np.array_equal(a, ref)
+    except ImportError:
+        pass
+    info, e = image_decoder(os.path.join(tex, "alps_field_1k.hdr"))
+    assert (info["w"], info["h"], info["float"]) == (1024, 512, True)
+    assert np.isfinite(e).all() and e.min() >= 0 and e.max() > 100 and 0.1 < e.mean() < 10     # a sunlit sky
