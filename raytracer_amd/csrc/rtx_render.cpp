@@ -1,6 +1,6 @@
 // C ABI (include/rtx.h): CastRays on the GPU — host orchestration of the wavefront path tracer.
 // Replaces RayCaster::CastRays / RenderBucket (reference RayTracer/RayCaster.cpp:697-1023, 1146-1314): buckets of
-// this rank -> pixel list -> passes of S samples per pixel through ray-gen / extend / shade / shadow / resolve ->
+// this rank -> pixel list -> passes of S samples per pixel through ray-gen / extend / shade / shadow (+ tail kernel) ->
 // film accumulation -> confidence-interval test -> refinement rounds.
 #include "rtx_internal.h"
 #include "pathstate.h"
@@ -299,7 +299,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     if (const char* e = std::getenv("RTX_AMD_TAIL_PATHS")) tailMax = std::min<uint32_t>(tailMax, (uint32_t)std::atol(e));   // 0 disables
     if (s->cfg.counting) tailMax = 0;   // node / triangle tallies exist in the counting build of extend_kernel only
 
-    // Overlap: shadow(k) + resolve(k) on a side stream beside extend(k+1); shade(k+1) waits for both. Either kernel
+    // Overlap: shadow(k) on a side stream beside extend(k+1); shade(k+1) waits for both. Either kernel
     // alone leaves most of the chip idle while its last rays finish (a launch costs ~0.3 ms beyond its throughput time).
     // Only for bounces of at most overlapMax paths: larger launches fill the chip on their own, and sharing it would
     // stretch the extend launches that the roofline figure is measured on.
@@ -315,7 +315,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     LaunchCfg sideCfg = s->cfg;
     sideCfg.stream = ph->sideStream;
     sideCfg.spill = ph->sideSpill;
-    bool sidePending = false;   // a resolve on the side stream that the main stream has not waited for yet
+    bool sidePending = false;   // a shadow launch on the side stream that the main stream has not waited for yet
 
     s->cancel.store(0);
     PassTimers tm{ph};
