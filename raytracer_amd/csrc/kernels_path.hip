@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
 #ifndef SHADOW_REFILL_MIN
 #define SHADOW_REFILL_MIN 16
 #endif
+// useTransmittance: bit 0 = Visible() with transmittance (else VisibleSimple), bit 1 = no early exit (parity checks)
 __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene sc, PathPool pool, SegQ q, int useTransmittance, uint2* spill,
                                                             uint32_t chunk) {
     __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene sc, PathPoo
             if (fin) {
                 intersect_lights(sc, s.r, s.best);
                 float T;
-                if (shadow_hop_end(sc, o, d, maxDist, s.best, useTransmittance != 0, hop, visibility, T)) {
+                if (shadow_hop_end(sc, o, d, maxDist, s.best, (useTransmittance & 1) != 0, hop, visibility, T)) {
                     pool.nee[(size_t)(code & 7u) * pool.capacity + (code >> 3)].w = T;
                     active = false;
                 } else {
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene sc, PathPoo
 #if SHADOW_ANYHIT
                     const int before = s.best.slot;
                     trav_leaf_test(s, sc, s.cur, RTX_HIT_FRONT_AND_BACK);
-                    if (s.best.slot != before && shadow_hit_decides(sc, s, maxDist, useTransmittance != 0)) {
+                    if (s.best.slot != before && (useTransmittance & 2) == 0 && shadow_hit_decides(sc, s, maxDist, (useTransmittance & 1) != 0)) {
                         s.cur = RTX_TRAV_DONE;   // the chain ends with 0 at this blocker (shadow_hop_end)
                         s.sp = 0;
                     } else

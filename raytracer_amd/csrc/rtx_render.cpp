@@ -303,6 +303,8 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     // alone leaves most of the chip idle while its last rays finish (a launch costs ~0.3 ms beyond its throughput time).
     // Only for bounces of at most overlapMax paths: larger launches fill the chip on their own, and sharing it would
     // stretch the extend launches that the roofline figure is measured on.
+    int shadowFlags = 0;   // bit 1: shadow hops run to their closest hit even when an earlier hit decides the chain
+    if (const char* e = std::getenv("RTX_AMD_SHADOW_EARLY_EXIT")) shadowFlags = std::atoi(e) != 0 ? 0 : 2;
     bool overlap = true;
     uint32_t overlapMax = 2u << 20;
     if (const char* e = std::getenv("RTX_AMD_OVERLAP")) overlap = std::atoi(e) != 0;
@@ -376,7 +378,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 if (cnt[1]) {
                     tm.nextItems = cnt[1];
                     tm.begin(1, sst);
-                    launch_shadow(s->dev, side ? sideCfg : s->cfg, pool, pool.qS, cnt[1], bounce <= 8 ? 1 : 0);   // useTransmittance (RayCaster.cpp:454)
+                    launch_shadow(s->dev, side ? sideCfg : s->cfg, pool, pool.qS, cnt[1], (bounce <= 8 ? 1 : 0) | shadowFlags);   // useTransmittance (RayCaster.cpp:454)
                     tm.end(sst);
                 }
                 if (side) {

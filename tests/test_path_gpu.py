@@ -154,3 +154,25 @@ def test_error_paths(small, rtx):
     big = synth.cerealbar_camera(4096, 4096)
     with pytest.raises(rtx.RtxError, match="overflows"):
         gs.render(big, render_params(spp_min=1))             # sampleIndex would overflow int (RayCaster.cpp:784)
+
+
+def test_scheduling_switches_do_not_change_results(small, monkeypatch):
+    """The shadow kernel's early exit, the side stream and the tail kernel are scheduling: per-sample radiance with each
+    of them switched off. Early exit and side stream: bit-identical. Tail kernel: its shading divides exactly where
+    shade_kernel uses the 2.5-ulp form, so a few long glass paths move."""
+    sd, cam, gs, osc = small
+    rp = render_params(spp_min=4, max_bounces=64)
+    base, st0 = gs.render_samples(cam, rp)
+    monkeypatch.setenv("RTX_AMD_SHADOW_EARLY_EXIT", "0")
+    full, st1 = gs.render_samples(cam, rp)
+    monkeypatch.delenv("RTX_AMD_SHADOW_EARLY_EXIT")
+    assert np.array_equal(base, full)
+    assert st1["rays_shadow"] > st0["rays_shadow"]                  # the exit does save hops
+    monkeypatch.setenv("RTX_AMD_OVERLAP", "0")
+    serial, _ = gs.render_samples(cam, rp)
+    monkeypatch.delenv("RTX_AMD_OVERLAP")
+    assert np.array_equal(base, serial)
+    monkeypatch.setenv("RTX_AMD_TAIL_PATHS", "0")
+    loop, _ = gs.render_samples(cam, rp)
+    monkeypatch.delenv("RTX_AMD_TAIL_PATHS")
+    assert frac_within(loop, base) >= 0.998
