@@ -53,8 +53,9 @@ int query_resident_blocks(int which);  // blocks per CU for kernel 'which' (0 ex
 struct PathPool;
 struct DevPhotonMap;
 // raygen and shade return their grid size: the geometry segq_scan needs for the queues they append to
+// initGuides: raygen also clears the first-hit guides and the pending-resolve marker (legacy mode; the path loop's first shade writes them)
 uint32_t launch_raygen(const DevCamera& cam, const PathPool& pool, const int* pixels, uint32_t nPix, int S, int sBase, int indexStride,
-                       const SegQ& qOut, uint32_t* queueOut, hipStream_t stream);
+                       const SegQ& qOut, uint32_t* queueOut, int initGuides, hipStream_t stream);
 uint32_t launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm, const SegQ& qIn,
                       const uint32_t* queueIn, uint32_t n, int bounce, int maxBounces, unsigned long long seed, int sBase, int S,
                       const int* pixels, const SegQ& qOut, uint32_t* queueOut, const SegQ& qShadow, int hasMicrofacet,

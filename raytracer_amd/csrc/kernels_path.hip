@@ -50,8 +50,10 @@ __device__ __forceinline__ void pixel_shifts(int x, int y, float& sx, float& sy)
     sy = (float)((double)(h2 & 0xFFFFFFFFULL) / 4294967296.0);
 }
 
+// initGuides: also clear the first-hit guides and the pending-resolve marker of every slot. The path loop does not
+// need it (its first shade writes all three for every path); the legacy kernel does.
 __global__ void raygen_kernel(DevCamera cam, PathPool pool, const int* __restrict__ pixels, uint32_t nPix, int S, int sBase,
-                              int indexStride, SegQ qOut, uint32_t* __restrict__ queueOut) {
+                              int indexStride, SegQ qOut, uint32_t* __restrict__ queueOut, int initGuides) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nSlots = nPix * (uint32_t)S;
     bool valid = false;
@@ -102,9 +104,11 @@ __global__ void raygen_kernel(DevCamera cam, PathPool pool, const int* __restric
             pool.L[slot] = make_float4(0.0f, 0.0f, 0.0f, RTX_BIG);
             pool.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
             pool.medium[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(PF_LAST_DELTA));
-            pool.pendBeta[slot] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);   // nothing to resolve yet (resolve_add)
-            pool.albedo[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            pool.normal[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (initGuides) {
+                pool.pendBeta[slot] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);   // nothing to resolve (resolve_add)
+                pool.albedo[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                pool.normal[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
             pool.samplePos[slot] = make_float2(samplePosX, samplePosY);
         }
     }
@@ -493,11 +497,12 @@ __global__ void film_resolve_kernel(rtx_film film, uint32_t n, int srgb, float* 
 
 // ---- launch wrappers -------------------------------------------------------------------------------------------
 uint32_t launch_raygen(const DevCamera& cam, const PathPool& pool, const int* pixels, uint32_t nPix, int S, int sBase, int indexStride,
-                       const SegQ& qOut, uint32_t* queueOut, hipStream_t stream) {
+                       const SegQ& qOut, uint32_t* queueOut, int initGuides, hipStream_t stream) {
     const uint32_t n = nPix * (uint32_t)S;
     if (!n) return 0;
     const uint32_t grid = (n + 255) / 256;
-    hipLaunchKernelGGL(raygen_kernel, dim3(grid), dim3(256), 0, stream, cam, pool, pixels, nPix, S, sBase, indexStride, qOut, queueOut);
+    hipLaunchKernelGGL(raygen_kernel, dim3(grid), dim3(256), 0, stream, cam, pool, pixels, nPix, S, sBase, indexStride, qOut, queueOut,
+                       initGuides);
     return grid;
 }
 uint32_t launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm, const SegQ& qIn,

@@ -126,7 +126,9 @@ __global__ __launch_bounds__(TRAV_BLOCK) void tail_kernel(DevScene sc, DevCamera
         haveVertex = false;
         if (needExtend) {
             needExtend = shade_body<MICRO, true>(sc, cam, pool, pm, slot, ray, hit, bounce, maxBounces, seed, sBase, S, pixels, SegQ{nullptr});
-            haveVertex = true;   // resolve_slot looks at the pending marker the body leaves
+            // the NEE entries are this vertex's only when the body left something pending (a path that ended on a miss
+            // or a light never reached its NEE loop: the entries then hold an older vertex's values)
+            haveVertex = pool.pendBeta[slot].w >= 0.0f;
             ++bounce;
         }
     }

@@ -335,7 +335,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
             uint32_t* qin = pool.queueA;
             uint32_t* qout = pool.queueB;
             SegQ sqIn = pool.qA, sqOut = pool.qB;
-            const uint32_t gridGen = launch_raygen(dc, pool, curPixels, nPix, Sp, sBase, stride, sqIn, qin, st);
+            const uint32_t gridGen = launch_raygen(dc, pool, curPixels, nPix, Sp, sBase, stride, sqIn, qin, legacy ? 1 : 0, st);
             launch_segq_scan(sqIn, gridGen, 256, 1, pool.totals, 2, st);
             uint32_t n = (uint32_t)(curValid * (size_t)Sp);   // = totals[2]: every valid pixel generates Sp paths
             out.paths += n;

@@ -101,7 +101,7 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
         float4 b4 = pool.beta[slot];
         float4 m4 = pool.medium[slot];
         f3 L = mk3(L4.x, L4.y, L4.z);
-        resolve_add(pool, slot, sc.n_lights, pm.n > 0, L);   // the NEE of the previous vertex (its shadow results are in)
+        if (bounce > 0) resolve_add(pool, slot, sc.n_lights, pm.n > 0, L);   // the NEE of the previous vertex (its shadow results are in)
         f3 beta = mk3(b4.x, b4.y, b4.z);
         float lastPdf = b4.w;
         uint32_t flags = __float_as_uint(m4.w);
@@ -128,6 +128,8 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
                 if (bounce == 0) {
                     const f3 vis = hasBackground ? backplate : envLight;
                     L = L + beta * (vis + bgEmit);
+                    pool.albedo[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // no first hit: no guides (raygen leaves them to this kernel)
+                    pool.normal[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 } else {
                     L = L + beta * (envLight + bgEmit);
                 }
