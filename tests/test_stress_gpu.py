@@ -1,0 +1,113 @@
+"""Odd shapes and extreme settings, GPU against the oracle through the C ABI: image sizes that are not multiples of the
+bucket or of 64 pixels, 1x1 images, no lights, eight lights (more shadow jobs than the tail kernel's quad holds in one
+round), an all-glass scene, tiny and huge coordinates, one-bounce limits, both shading modes."""
+import numpy as np
+import pytest
+
+from raytracer_amd import _ffi
+from raytracer_amd.scene import Light, Material, Mesh, SceneData, make_camera, render_params
+from tests.oracle_ffi import OracleScene
+
+pytestmark = pytest.mark.gpu
+
+
+def box(lo, hi, material):
+    lo, hi = np.asarray(lo, np.float32), np.asarray(hi, np.float32)
+    c = np.array([[lo[0] if not i & 1 else hi[0], lo[1] if not i & 2 else hi[1], lo[2] if not i & 4 else hi[2]] for i in range(8)], np.float32)
+    f = [[0, 2, 1], [1, 2, 3], [4, 5, 6], [5, 7, 6], [0, 1, 4], [1, 5, 4], [2, 6, 3], [3, 6, 7], [0, 4, 2], [2, 4, 6], [1, 3, 5], [3, 7, 5]]
+    return Mesh(c, f, material=material)
+
+
+def room(n_lights=3, scale=1.0, glass_only=False):
+    sd = SceneData()
+    sd.materials = [
+        Material(diffuse=(0.7, 0.7, 0.65), specular=(0.2, 0.2, 0.2), glossiness=40.0),
+        Material(diffuse=(0.0, 0.0, 0.0), specular=(0.9, 0.9, 0.9), refraction=(0.95, 0.95, 0.95), ior=1.5, glossiness=1e4,
+                 absorption=(0.3, 0.05, 0.05)),
+        Material(diffuse=(0.1, 0.1, 0.1), specular=(0.6, 0.6, 0.6), reflection=(0.8, 0.8, 0.8), glossiness=500.0),
+    ]
+    s = np.float32(scale)
+    floor = np.array([[-4, 0, -4], [4, 0, -4], [4, 0, 4], [-4, 0, 4]], np.float32) * s
+    sd.meshes = [Mesh(floor, [[0, 2, 1], [0, 3, 2]], material=1 if glass_only else 0)]
+    sd.meshes.append(box(np.array([-1.5, 0.0, -0.5]) * s, np.array([-0.5, 1.0, 0.5]) * s, 1))
+    sd.meshes.append(box(np.array([0.4, 0.0, -0.6]) * s, np.array([1.4, 0.8, 0.4]) * s, 1 if glass_only else 2))
+    sd.meshes.append(Mesh.sphere(xform=np.array([0.4 * s, 0, 0, 0.0, 0, 0.4 * s, 0, 1.6 * s, 0, 0, 0.4 * s, 0.3 * s], np.float32),
+                                 material=1 if glass_only else 0))
+    rng = np.random.default_rng(4)
+    sd.lights = [Light(tuple(np.array([rng.uniform(-3, 3), rng.uniform(2.5, 4), rng.uniform(-3, 3)]) * s),
+                       tuple(rng.uniform(4, 12, 3) * s * s), size=(0.3 * s if k % 2 == 0 else 0.0)) for k in range(n_lights)]
+    sd.environment = (0.15, 0.18, 0.22)
+    return sd
+
+
+def cam_for(scale, w, h):
+    return make_camera((0.3 * scale, 1.7 * scale, 4.5 * scale), (0, 0.5 * scale, 0), fov=40, focaldist=4.5 * scale, dof=0.0, width=w, height=h)
+
+
+def agree(g, o, tol=1e-3):
+    d = np.abs(g[..., :3] - o[..., :3]).max(-1)
+    return float((d <= tol * (1 + np.abs(o[..., :3]).max(-1))).mean())
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 5), (33, 17), (70, 50)])
+def test_odd_image_sizes(rtx, w, h):
+    sd = room()
+    gs, osc = rtx.Scene(sd), OracleScene(sd)
+    cam = cam_for(1.0, w, h)
+    rp = render_params(spp_min=3, max_bounces=16)
+    g, st = gs.render_samples(cam, rp)
+    o = osc.render_samples(cam, rp)
+    assert g.shape == o.shape == (h, w, 3, 4) and st["rays_primary"] == w * h * 3
+    assert agree(g, o) >= 0.99 and np.isfinite(g).all()
+    img, ref = gs.render(cam, rp), osc.render(cam, rp)
+    assert np.array_equal(img["samples"], ref["samples"])
+    assert np.abs(img["linear"] - ref["linear"]).mean() <= 0.02 * (ref["linear"].mean() + 1e-3)
+
+
+@pytest.mark.parametrize("mode", [_ffi.SHADING_PATH, _ffi.SHADING_LEGACY])
+@pytest.mark.parametrize("n_lights", [0, 1, 8])
+def test_light_counts(rtx, mode, n_lights):
+    """0 lights: no shadow queue at all; 8 lights: three rounds of shadow jobs per vertex in the tail kernel."""
+    sd = room(n_lights)
+    gs, osc = rtx.Scene(sd), OracleScene(sd)
+    cam = cam_for(1.0, 48, 32)
+    rp = render_params(spp_min=4, max_bounces=12, shading_mode=mode)
+    g, st = gs.render_samples(cam, rp)
+    o = osc.render_samples(cam, rp)
+    assert np.isfinite(g).all() and agree(g, o) >= 0.99
+    assert (st["rays_shadow"] == 0) == (n_lights == 0)
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 1e2, 3e3])
+def test_scene_scale(rtx, scale):
+    """Millimetre-sized to kilometre-sized copies of the same room: the quantised node frames, the 1e-4 offsets and the
+    biases are absolute lengths in the reference, so the images differ between scales - GPU and oracle must not.
+    At 3e3 the coordinates reach 1.2e4, where one fp32 ulp (1e-3) is larger than the reference's 1e-4 ray offsets: rays
+    start on their own surface and every second hit is decided by the last bit of t (shadow acne, in the reference
+    too). There only the well-conditioned part is compared: primary hits, finiteness, overall level."""
+    sd = room(3, scale)
+    gs, osc = rtx.Scene(sd), OracleScene(sd)
+    cam = cam_for(scale, 40, 28)
+    for mode in (_ffi.SHADING_PATH, _ffi.SHADING_LEGACY):
+        rp = render_params(spp_min=3, max_bounces=12, shading_mode=mode)
+        g, _ = gs.render_samples(cam, rp)
+        o = osc.render_samples(cam, rp)
+        assert np.isfinite(g).all()
+        assert (np.abs(g[..., 3] - o[..., 3]) <= 1e-4 * np.abs(o[..., 3])).mean() >= 0.995
+        if scale < 1e3:   # at 1e2 an ulp of the coordinates (3e-5) is already a third of the offsets: a few more flips
+            assert agree(g, o, 2e-3) >= (0.985 if scale < 50 else 0.97), (scale, mode)
+        else:
+            assert abs(g[..., :3].mean() - o[..., :3].mean()) <= 0.25 * o[..., :3].mean(), (scale, mode)
+
+
+def test_all_glass_long_paths(rtx):
+    """Every surface transmissive: paths run to the bounce limit, shadow chains to their 8-hop limit."""
+    sd = room(2, 1.0, glass_only=True)
+    gs, osc = rtx.Scene(sd), OracleScene(sd)
+    cam = cam_for(1.0, 40, 28)
+    for mb in (1, 2, 64):
+        rp = render_params(spp_min=4, max_bounces=mb)
+        g, st = gs.render_samples(cam, rp)
+        o = osc.render_samples(cam, rp)
+        assert np.isfinite(g).all() and agree(g, o, 2e-3) >= 0.985, mb
+    assert st["rays_bounce"] > st["rays_primary"] // 2 and st["rays_shadow"] > 0
