@@ -186,6 +186,10 @@ __device__ __forceinline__ void trav_init(TravState& s, const DevScene& sc, cons
     s.bestPrim = 0xFFFFFFFFu;
     s.cur = sc.root;        // RTX_EMPTY_CHILD for an empty scene == DONE
     s.sp = 0;
+    // NaN or infinite origin / direction, NaN limit: no hit, as the reference's box test at the root decides for such a
+    // ray (every comparison of scene_box.cpp:8-46 fails). The slab test here drops NaNs instead, so it has to be said.
+    const float probe = (r.ox + r.oy + r.oz) + (r.dx + r.dy + r.dz);
+    if (!(fabsf(probe) < __builtin_inff()) || r.tmax != r.tmax) s.cur = RTX_TRAV_DONE;
 }
 __device__ __forceinline__ bool trav_is_inner(uint32_t cur) { return (cur & RTX_LEAF_FLAG) == 0u; }
 

@@ -111,3 +111,74 @@ def test_all_glass_long_paths(rtx):
         o = osc.render_samples(cam, rp)
         assert np.isfinite(g).all() and agree(g, o, 2e-3) >= 0.985, mb
     assert st["rays_bounce"] > st["rays_primary"] // 2 and st["rays_shadow"] > 0
+
+
+def test_empty_and_degenerate_scenes(rtx):
+    """No geometry at all, and geometry that no ray can hit (zero-area triangles): every path leaves for the
+    environment at once; nothing fails, GPU and oracle agree exactly."""
+    for meshes in ([], [Mesh(np.array([[0, 0, 0], [1, 1, 1], [2, 2, 2], [1, 1, 1]], np.float32), [[0, 1, 2], [1, 1, 1], [0, 3, 1]], material=0)]):
+        sd = SceneData()
+        sd.materials = [Material()]
+        sd.meshes = meshes
+        sd.lights = [Light((0, 3, 0), (5, 5, 5), size=0.0)]     # a point light: nothing for a camera ray to hit
+        sd.environment = (0.2, 0.3, 0.4)
+        gs, osc = rtx.Scene(sd), OracleScene(sd)
+        cam = make_camera((0, 1, 5), (0, 0, 0), fov=50, width=20, height=12)
+        for mode in (_ffi.SHADING_PATH, _ffi.SHADING_LEGACY):
+            rp = render_params(spp_min=2, max_bounces=8, shading_mode=mode)
+            g, st = gs.render_samples(cam, rp)
+            o = osc.render_samples(cam, rp)
+            assert np.array_equal(g, o) and np.allclose(g[..., :3], [0.2, 0.3, 0.4]) and (g[..., 3] > 1e29).all()
+            assert st["rays_bounce"] == 0 and st["rays_shadow"] == 0
+        rays = np.zeros(3, _ffi.np_dtypes()[0])
+        rays["o"], rays["d"], rays["tmax"] = (0, 0, 5), (0, 0, -1), 1e30
+        assert (gs.trace_closest(rays, _ffi.HIT_FRONT_AND_BACK)["obj"] == -1).all()
+
+
+def test_adaptive_rounds_with_ragged_limits(rtx):
+    """spp_max that is no multiple of spp_min (the last round is shorter), a wide Gaussian filter on an image smaller
+    than its support, one sample per pass."""
+    sd = room()
+    gs, osc = rtx.Scene(sd), OracleScene(sd)
+    cam = cam_for(1.0, 19, 13)
+    rp = render_params(spp_min=3, spp_max=11, ci_halfwidth=0.02, max_bounces=6, filter_type=_ffi.FILTER_GAUSSIAN, filter_radius=3.0,
+                       samples_per_pass=1)
+    g, o = gs.render(cam, rp), osc.render(cam, rp)
+    assert set(np.unique(o["samples"])) <= {3, 6, 9, 11} and (o["samples"] == 11).any()
+    assert (g["samples"] == o["samples"]).mean() >= 0.98
+    same = g["samples"] == o["samples"]
+    assert np.abs(g["linear"] - o["linear"])[same].mean() <= 0.02 * o["linear"].mean()
+
+
+def test_non_finite_rays_are_misses(rtx):
+    """NaN / infinite origins, directions and limits: 'no hit' for that ray, the rest of the batch unaffected."""
+    sd = room()
+    gs, osc = rtx.Scene(sd), OracleScene(sd)
+    rays = np.zeros(8, _ffi.np_dtypes()[0])
+    rays["o"], rays["d"], rays["tmax"] = (0.1, 3.0, 0.2), (0, -1, 0), 1e30
+    rays["o"][1, 0] = np.nan
+    rays["d"][2] = (np.nan, -1, 0)
+    rays["d"][3] = (0, 0, 0)
+    rays["o"][4, 1] = np.inf
+    rays["tmax"][5] = 0.0
+    rays["tmax"][6] = -1.0
+    g = gs.trace_closest(rays, _ffi.HIT_FRONT_AND_BACK)
+    o = osc.trace_closest(rays, _ffi.HIT_FRONT_AND_BACK)
+    assert np.array_equal(g["obj"], o["obj"]) and g["obj"][0] >= 0 and g["obj"][7] >= 0
+    assert (g["obj"][1:7] == -1).all()
+    assert np.array_equal(g["t"][[0, 7]], o["t"][[0, 7]])
+
+
+def test_photons_without_sources_or_receivers(rtx):
+    """No light to emit from, and a scene without a single diffuse surface to store photons on: empty maps, and a render
+    that uses them changes nothing."""
+    for n_lights, glass_only in ((0, False), (2, True)):
+        sd = room(n_lights, 1.0, glass_only)
+        gs = rtx.Scene(sd)
+        ph = rtx.Photons(gs, num_photons=20000)
+        info = ph.info()
+        assert info["n_global"] == 0 and info["n_caustic"] == 0
+        cam = cam_for(1.0, 24, 16)
+        a, _ = gs.render_samples(cam, render_params(spp_min=2, max_bounces=6, use_photons=1), ph)
+        b, _ = gs.render_samples(cam, render_params(spp_min=2, max_bounces=6))
+        assert np.array_equal(a, b)
