@@ -60,6 +60,7 @@ extern "C" {
 #define RTX_FILTER_GAUSSIAN 1
 #define RTX_FILTER_MITCHELL 2
 #define RTX_FILTER_LANCZOS 3
+#define RTX_MAX_FILTER_RADIUS 16.0f /* largest filter_radius accepted (the reference's supports are 1 .. 2 pixels, :84-92) */
 
 typedef struct rtx_scene rtx_scene;   /* opaque: flattened BVH + triangles + materials + lights in HBM */
 typedef struct rtx_photons rtx_photons; /* opaque: photon maps + hash grids in HBM                      */

@@ -358,6 +358,11 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
             err = "mesh " + std::to_string(m) + ": missing vertex/face arrays";
             return false;
         }
+        for (int k = 0; k < 12; ++k)
+            if (!std::isfinite(md.xform[k])) {
+                err = "object " + std::to_string(m) + ": non-finite transform";
+                return false;
+            }
         if (md.material >= desc->n_materials) {
             err = "mesh " + std::to_string(m) + ": material index out of range";
             return false;
@@ -446,7 +451,13 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
                     return false;
                 }
                 if (ident) std::memcpy(t.v[k], md.v + 3 * (size_t)vi, 12);
-                else xf_point(md.xform, md.v + 3 * (size_t)vi, t.v[k]);
+                else {
+                    xf_point(md.xform, md.v + 3 * (size_t)vi, t.v[k]);
+                    if (!std::isfinite(t.v[k][0]) || !std::isfinite(t.v[k][1]) || !std::isfinite(t.v[k][2])) {
+                        err = "mesh " + std::to_string(m) + ": vertex overflows under its transform";
+                        return false;
+                    }
+                }
             }
             if (md.vn && md.nvn > 0) {
                 const int* fn = (md.fn ? md.fn : md.f) + 3 * (size_t)f;

@@ -19,8 +19,10 @@ __device__ inline f3 estimate_irradiance(const DevPhotonMap& pm, f3 pos, f3 norm
     int cx0 = (int)floorf((pos.x - radius - pm.gmin[0]) / pm.cell), cx1 = (int)floorf((pos.x + radius - pm.gmin[0]) / pm.cell);
     int cy0 = (int)floorf((pos.y - radius - pm.gmin[1]) / pm.cell), cy1 = (int)floorf((pos.y + radius - pm.gmin[1]) / pm.cell);
     int cz0 = (int)floorf((pos.z - radius - pm.gmin[2]) / pm.cell), cz1 = (int)floorf((pos.z + radius - pm.gmin[2]) / pm.cell);
-    cx0 = max(cx0, 0); cy0 = max(cy0, 0); cz0 = max(cz0, 0);
-    cx1 = min(cx1, pm.gx - 1); cy1 = min(cy1, pm.gy - 1); cz1 = min(cz1, pm.gz - 1);
+    // cell_of clamps photons into the border cells, so a query beyond the grid (photons handed in through
+    // rtx_photon_set need not lie inside the scene box) searches the border cells too; the distance test decides
+    cx0 = min(max(cx0, 0), pm.gx - 1); cy0 = min(max(cy0, 0), pm.gy - 1); cz0 = min(max(cz0, 0), pm.gz - 1);
+    cx1 = max(min(cx1, pm.gx - 1), 0); cy1 = max(min(cy1, pm.gy - 1), 0); cz1 = max(min(cz1, pm.gz - 1), 0);
     // pass 1: count candidates and find the K-th smallest (d2, index) by repeated threshold refinement:
     // a max-heap of K entries would need K registers; instead bisect on the key, which is exact because keys
     // are (d2 bits, index) pairs compared as 64-bit integers.

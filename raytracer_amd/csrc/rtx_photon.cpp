@@ -99,6 +99,10 @@ int rtx_photon_build(rtx_scene* s, const rtx_photon_params* pp, rtx_photons** ou
     *out = nullptr;
     if (pp->num_photons < 0 || pp->max_bounces < 0 || pp->max_bounces > 3) return rtx_fail(RTX_ERR_INVALID, "bad photon parameters");
     if ((long long)pp->num_photons * 4 > 0xFFFFFFFFLL) return rtx_fail(RTX_ERR_TOO_LARGE, "more than 2^30 photons");
+    if (pp->first_photon < 0) return rtx_fail(RTX_ERR_INVALID, "first_photon must be >= 0");
+    // <= 0 selects the scene-derived radius; NaN / infinity would reach the grid dimensions
+    if (!std::isfinite(pp->photon_radius) || !std::isfinite(pp->caustic_radius))
+        return rtx_fail(RTX_ERR_INVALID, "photon_radius / caustic_radius must be finite");
     const int stride = pp->photon_stride > 0 ? pp->photon_stride : 1;
     rtx_photons* p = new rtx_photons();
     p->scene = s;
@@ -183,6 +187,7 @@ int64_t rtx_photon_download(const rtx_photons* p, int which, rtx_photon* out, si
     const PhotonSet& s = p->set[which];
     const size_t n = std::min<size_t>(capacity, s.n);
     if (!n) return 0;
+    if (!out) return rtx_fail(RTX_ERR_INVALID, "out is NULL");
     std::vector<DevPhotonRec> tmp(n);
     if (hipMemcpy(tmp.data(), s.raw, n * sizeof(DevPhotonRec), hipMemcpyDeviceToHost) != hipSuccess) return rtx_fail(RTX_ERR_HIP, "copy failed");
     for (size_t i = 0; i < n; ++i) {
@@ -218,6 +223,7 @@ int rtx_photon_set(rtx_photons* p, int which, const void* photons_dev, size_t n,
 int rtx_photon_estimate(rtx_photons* p, int which, const float* positions, const float* normals, size_t n, float* irradiance) {
     if (!p || which < 0 || which > 1 || (n && (!positions || !normals || !irradiance))) return rtx_fail(RTX_ERR_INVALID, "bad argument");
     if (!n) return RTX_OK;
+    if (n > 0x7FFFFFFFull) return rtx_fail(RTX_ERR_TOO_LARGE, "more than 2^31 query points in one call");
     DevPhotonMap pm;
     photon_device_map(p, which, pm);
     float *dp = nullptr, *dn = nullptr, *dout = nullptr;

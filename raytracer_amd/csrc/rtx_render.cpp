@@ -209,6 +209,11 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     if (!spec && (rp->spp_min < 1 || rp->spp_max < rp->spp_min)) return rtx_fail(RTX_ERR_INVALID, "need 1 <= spp_min <= spp_max");
     if (spec && (spec->nSamples < 1 || spec->sampleBase < 0)) return rtx_fail(RTX_ERR_INVALID, "need n_samples >= 1, sample_base >= 0");
     if (rp->max_bounces < 1) return rtx_fail(RTX_ERR_INVALID, "max_bounces must be >= 1");
+    if (rp->shading_mode != RTX_SHADING_PATH && rp->shading_mode != RTX_SHADING_LEGACY)
+        return rtx_fail(RTX_ERR_INVALID, "unknown shading_mode");
+    if (rp->filter_type < RTX_FILTER_TENT || rp->filter_type > RTX_FILTER_LANCZOS) return rtx_fail(RTX_ERR_INVALID, "unknown filter_type");
+    // every sample splats (2r+1)^2 pixels: an unbounded radius would turn the film kernel into a frame-sized loop per sample
+    if (!(rp->filter_radius <= RTX_MAX_FILTER_RADIUS)) return rtx_fail(RTX_ERR_INVALID, "filter_radius must be <= RTX_MAX_FILTER_RADIUS (<= 0: the filter's default support)");
     const int world = rp->world > 0 ? rp->world : 1;
     if (rp->rank < 0 || rp->rank >= world) return rtx_fail(RTX_ERR_INVALID, "rank out of range");
     DevCamera dc;
@@ -664,7 +669,8 @@ void rtx_film_destroy(rtx_film* film, rtx_pixel_stats* stats) {
 
 int rtx_render(rtx_scene* s, const rtx_camera* cam, const rtx_render_params* rp, rtx_photons* photons, float* linear_rgb,
                unsigned char* rgb8, float* z, int* samples, rtx_stats* stats) {
-    if (!s || !cam) return rtx_fail(RTX_ERR_INVALID, "NULL argument");
+    if (!s || !cam || !rp) return rtx_fail(RTX_ERR_INVALID, "NULL argument");
+    if (cam->width <= 0 || cam->height <= 0) return rtx_fail(RTX_ERR_INVALID, "invalid camera");
     const size_t n = (size_t)cam->width * cam->height;
     rtx_film f;
     std::vector<void*> owned;
@@ -681,6 +687,8 @@ int rtx_render_samples(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                        rtx_stats* stats) {
     if (!s || !cam || !rp || !out) return rtx_fail(RTX_ERR_INVALID, "NULL argument");
     if (rp->spp_max != rp->spp_min) return rtx_fail(RTX_ERR_INVALID, "rtx_render_samples needs a fixed sample count");
+    if (rp->spp_min < 1) return rtx_fail(RTX_ERR_INVALID, "need 1 <= spp_min <= spp_max");
+    if (cam->width <= 0 || cam->height <= 0) return rtx_fail(RTX_ERR_INVALID, "invalid camera");
     const size_t n = (size_t)cam->width * cam->height;
     rtx_film f;
     std::vector<void*> owned;
