@@ -148,6 +148,10 @@ inline bool is_identity(const float* M) {
     return std::memcmp(M, I, sizeof(I)) == 0;
 }
 
+inline double det33(const float* M) {
+    const double a = M[0], b = M[1], c = M[2], d = M[4], e = M[5], f = M[6], g = M[8], h = M[9], i = M[10];
+    return a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+}
 inline void invert34(const float* M, float* R) {
     double a = M[0], b = M[1], c = M[2], d = M[4], e = M[5], f = M[6], g = M[8], h = M[9], i = M[10];
     double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
@@ -204,11 +208,12 @@ struct Emitter {
         }
 
         const rtx_mesh_desc& m = desc->meshes[t.obj];
+        const bool mir = (out.objs[t.obj].flags & OBJ_MIRRORED) != 0u;   // v1 and v2 are exchanged in t.v
         TriAttr a;
         std::memset(&a, 0, sizeof(a));
         if (m.vn && m.nvn > 0) {
             const int* fn = (m.fn ? m.fn : m.f) + 3 * (size_t)t.face;
-            float* dst[3] = {a.n0, a.n1, a.n2};
+            float* dst[3] = {a.n0, mir ? a.n2 : a.n1, mir ? a.n1 : a.n2};
             for (int k = 0; k < 3; ++k) {
                 const float* n = m.vn + 3 * (size_t)fn[k];
                 // normals go to world space by the inverse-transpose (Node::FromNodeCoords); the transform is
@@ -225,7 +230,7 @@ struct Emitter {
         }
         if (m.vt && m.nvt > 0) {
             const int* ft = (m.ft ? m.ft : m.f) + 3 * (size_t)t.face;
-            float* dst[3] = {a.uv0, a.uv1, a.uv2};
+            float* dst[3] = {a.uv0, mir ? a.uv2 : a.uv1, mir ? a.uv1 : a.uv2};
             for (int k = 0; k < 3; ++k) {
                 const float* uv = m.vt + 3 * (size_t)ft[k];
                 dst[k][0] = uv[0]; dst[k][1] = uv[1];
@@ -393,6 +398,13 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
         ObjRec& o = out.objs[m];
         o.material = md.material;
         o.flags = ((md.vn && md.nvn > 0) ? OBJ_HAS_NORMALS : 0u) | ((md.vt && md.nvt > 0) ? OBJ_HAS_TEXCOORDS : 0u);
+        // The reference intersects in object space and takes GN = normalize(itm^T (e1 x e2)) to the world
+        // (IntersectNodeAdapter.h:62,93). World-space edges give (M e1) x (M e2) = det(M) M^-T (e1 x e2): under a
+        // mirroring transform the baked triangle would face the other way. Exchanging v1 and v2 (and their attributes)
+        // restores the reference's geometric normal and front/back decision; the barycentrics (u, v) swap with them.
+        const bool mirrored = md.kind == RTX_OBJ_MESH && !ident && det33(md.xform) < 0.0;
+        if (mirrored) o.flags |= OBJ_MIRRORED;
+        if (md.kind == RTX_OBJ_MESH && !ident) o.flags |= OBJ_TRANSFORMED;
         o.face_base = faceBase[m];
         if (md.kind != RTX_OBJ_MESH) {
             // Sphere: GetBoundBox = [-1,1]^3, Plane: [-1,1]^2 x {0}; corners to root coordinates
@@ -450,10 +462,11 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
                     err = "mesh " + std::to_string(m) + ": vertex index out of range";
                     return false;
                 }
-                if (ident) std::memcpy(t.v[k], md.v + 3 * (size_t)vi, 12);
+                float* dstv = t.v[(mirrored && k) ? 3 - k : k];
+                if (ident) std::memcpy(dstv, md.v + 3 * (size_t)vi, 12);
                 else {
-                    xf_point(md.xform, md.v + 3 * (size_t)vi, t.v[k]);
-                    if (!std::isfinite(t.v[k][0]) || !std::isfinite(t.v[k][1]) || !std::isfinite(t.v[k][2])) {
+                    xf_point(md.xform, md.v + 3 * (size_t)vi, dstv);
+                    if (!std::isfinite(dstv[0]) || !std::isfinite(dstv[1]) || !std::isfinite(dstv[2])) {
                         err = "mesh " + std::to_string(m) + ": vertex overflows under its transform";
                         return false;
                     }

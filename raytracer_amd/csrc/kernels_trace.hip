@@ -215,8 +215,11 @@ __global__ void expand_hits_kernel(DevScene sc, const float4* __restrict__ rays,
         o.mtl_id = s.mtlID;
         o.front = s.front ? 1 : 0;
         o.light = s.light;
-        o.bu = h.u;
-        o.bv = h.v;
+        // a mirrored object's triangles are baked with v1 and v2 exchanged (bvh_build.cpp): report the barycentrics in
+        // the caller's vertex order
+        const bool mirrored = s.obj >= 0 && (sc.objs[s.obj].flags & OBJ_MIRRORED) != 0u;
+        o.bu = mirrored ? h.v : h.u;
+        o.bv = mirrored ? h.u : h.v;
         o.p[0] = s.p.x; o.p[1] = s.p.y; o.p[2] = s.p.z;
         o.N[0] = s.N.x; o.N[1] = s.N.y; o.N[2] = s.N.z;
         o.GN[0] = s.GN.x; o.GN[1] = s.GN.y; o.GN[2] = s.GN.z;

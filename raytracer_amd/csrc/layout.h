@@ -58,6 +58,8 @@ static_assert(sizeof(TriAttr) == 64, "TriAttr must be 64 bytes");
 
 #define OBJ_HAS_NORMALS 1u
 #define OBJ_HAS_TEXCOORDS 2u
+#define OBJ_TRANSFORMED 8u   // the object's transform is not the identity (its triangles are baked to world space)
+#define OBJ_MIRRORED 4u   // the object's transform has a negative determinant: its triangles are baked with v1 and v2 exchanged
 struct ObjRec {
     int material;           // index into materials, -1 = none
     uint32_t flags;

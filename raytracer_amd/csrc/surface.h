@@ -172,7 +172,23 @@ __device__ __forceinline__ void resolve_triangle(const DevScene& sc, const RayT&
     } else {
         s.uvw = mk3(0.0f);
     }
-    if (len2_3(s.dpdu) < RTX_EPS || len2_3(s.dpdv) < RTX_EPS) {
+    if (o.flags & OBJ_TRANSFORMED) {
+        // The reference builds this fallback frame in object space, around the object-space geometric normal, and
+        // takes it to the world as vectors (objects.cpp:233-240, then Node::FromNodeCoords). GN = normalize(M^-T n)
+        // gives n back as normalize(M^T GN); the length test is on the object-space derivatives M^-1 dpdu.
+        const ObjXform& X = sc.objXf[obj];
+        const float* F = X.fwd;
+        if (len2_3(xf_vec3(X.inv, s.dpdu)) < RTX_EPS || len2_3(xf_vec3(X.inv, s.dpdv)) < RTX_EPS) {
+            const f3 n = normalized3(mk3(F[0] * GN.x + F[4] * GN.y + F[8] * GN.z, F[1] * GN.x + F[5] * GN.y + F[9] * GN.z,
+                                         F[2] * GN.x + F[6] * GN.y + F[10] * GN.z));
+            f3 tangent = (fabsf(n.x) > 0.5f) ? mk3(-n.y, n.x, 0.0f) : mk3(0.0f, -n.z, n.y);
+            tangent = normalized3(tangent);
+            f3 bitangent = cross3(n, tangent);
+            bitangent = normalized3(bitangent);
+            s.dpdu = xf_vec3(F, tangent);
+            s.dpdv = xf_vec3(F, bitangent);
+        }
+    } else if (len2_3(s.dpdu) < RTX_EPS || len2_3(s.dpdv) < RTX_EPS) {
         f3 tangent = (fabsf(GN.x) > 0.5f) ? mk3(-GN.y, GN.x, 0.0f) : mk3(0.0f, -GN.z, GN.y);
         tangent = normalized3(tangent);
         f3 bitangent = cross3(GN, tangent);

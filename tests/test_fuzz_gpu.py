@@ -1,0 +1,102 @@
+"""Differential fuzzing (tools/fuzz_parity.py) as regression tests: random scenes through the C ABI and through the
+oracle. The seeds kept here are the ones that found defects (mirrored transforms baked with the wrong facing, the
+tangent frame of a transformed mesh without usable texture coordinates) plus a spread of ordinary ones; run the tool
+itself for more."""
+import numpy as np
+import pytest
+
+from raytracer_amd import _ffi
+from raytracer_amd.scene import Light, Material, Mesh, SceneData, TexMap, make_camera, render_params
+from tests.oracle_ffi import OracleScene
+from tools.fuzz_parity import agree, box_mesh, rand_scene
+
+pytestmark = pytest.mark.gpu
+
+MIRROR = np.array([-0.7, 0.1, 0.0, 0.2, 0.1, 0.8, 0.2, 0.9, 0.0, -0.3, 0.6, -0.4], np.float32)   # det < 0
+
+
+def grid_rays(n=24):
+    ray_dt, _, _ = _ffi.np_dtypes()
+    rng = np.random.default_rng(2)
+    r = np.zeros(n * n, dtype=ray_dt)
+    r["o"] = np.array([0.5, 1.4, 4.0], np.float32) + rng.uniform(-0.3, 0.3, (n * n, 3)).astype(np.float32)
+    tgt = np.stack(np.meshgrid(np.linspace(-1.2, 1.6, n), np.linspace(-0.2, 2.0, n)), -1).reshape(-1, 2)
+    d = np.concatenate([tgt, np.full((n * n, 1), -0.4)], 1).astype(np.float32) - r["o"]
+    r["d"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    r["tmax"] = 1e30
+    return r
+
+
+@pytest.mark.parametrize("with_normals", [False, True])
+def test_mirrored_transform_closest_hit(rtx, with_normals):
+    """The reference intersects in object space and carries the normal to the world by the inverse transpose
+    (IntersectNodeAdapter.h:62,93): under a mirroring transform front/back, GN and the barycentrics must still be the
+    object's own, not those of the world-space winding."""
+    rng = np.random.default_rng(3)
+    sd = SceneData()
+    sd.materials = [Material()]
+    m = box_mesh(rng, 0, MIRROR)
+    if with_normals:
+        m.vn = (m.v / np.linalg.norm(m.v, axis=1, keepdims=True) + rng.normal(scale=0.1, size=m.v.shape)).astype(np.float32)
+    sd.meshes = [m]
+    gs, osc = rtx.Scene(sd), OracleScene(sd)
+    rays = grid_rays()
+    for side in (_ffi.HIT_FRONT, _ffi.HIT_BACK, _ffi.HIT_FRONT_AND_BACK):
+        g, o = gs.trace_closest(rays, hit_side=side), osc.trace_closest(rays, hit_side=side)
+        hit = o["obj"] >= 0
+        assert hit.sum() > 50 or side == _ffi.HIT_BACK
+        same = (g["obj"] == o["obj"]) & (g["face"] == o["face"])
+        assert same.mean() >= 0.995                                    # object-space vs world-space edges: a grazed edge may differ
+        k = same & hit
+        assert (g["front"][k] == o["front"][k]).all()
+        assert np.allclose(g["t"][k], o["t"][k], rtol=2e-5)
+        for f in ("GN", "N"):
+            assert np.abs(g[f][k] - o[f][k]).max() <= 2e-5, f
+        assert np.abs(g["bu"][k] - o["bu"][k]).max() <= 2e-4 and np.abs(g["bv"][k] - o["bv"][k]).max() <= 2e-4
+        assert np.abs(g["uvw"][k] - o["uvw"][k]).max() <= 2e-4
+        assert np.abs(g["dpdu"][k] - o["dpdu"][k]).max() <= 1e-3 and np.abs(g["dpdv"][k] - o["dpdv"][k]).max() <= 1e-3
+    if not with_normals:                                              # seen from outside a closed box every hit is a front hit
+        g = gs.trace_closest(rays, hit_side=_ffi.HIT_FRONT_AND_BACK)
+        assert (g["front"][g["obj"] >= 0] == 1).all()
+
+
+def test_tangent_frame_of_transformed_mesh(rtx):
+    """Faces whose texture coordinates are degenerate take their tangent frame from the geometric normal — in object
+    space, then through the node transform (objects.cpp:233-240). Seen through a bump map."""
+    rng = np.random.default_rng(5)
+    sd = SceneData()
+    bump = rng.uniform(0, 1, (16, 16, 3)).astype(np.float32)
+    sd.texmaps = [TexMap(bump)]
+    sd.materials = [Material(diffuse=(0.8, 0.7, 0.6), specular=(0.3, 0.3, 0.3), glossiness=50.0, bump_tex=0, bump_scale=1.5)]
+    xf = np.array([0.5, 0.2, 0.0, 0.0, -0.1, 0.4, 0.3, 0.8, 0.1, -0.2, 0.6, 0.0], np.float32)
+    sd.meshes = [box_mesh(rng, 0, xf), box_mesh(rng, 0, MIRROR + np.array([0, 0, 0, 1.6] + [0] * 8, np.float32))]
+    nouv = box_mesh(rng, 0, xf + np.array([0, 0, 0, -1.6] + [0] * 8, np.float32))
+    nouv.vt = None                                                    # no texture coordinates at all
+    sd.meshes.append(nouv)
+    sd.lights = [Light((2.0, 4.0, 3.0), (30, 30, 30), size=0.0)]
+    sd.environment = (0.2, 0.2, 0.2)
+    gs, osc = rtx.Scene(sd), OracleScene(sd)
+    rays = grid_rays()
+    g, o = gs.trace_closest(rays, hit_side=_ffi.HIT_FRONT), osc.trace_closest(rays, hit_side=_ffi.HIT_FRONT)
+    k = (g["obj"] == o["obj"]) & (g["face"] == o["face"]) & (o["obj"] >= 0)
+    assert k.sum() > 100 and len(set(o["obj"][k].tolist())) == 3
+    assert np.abs(g["dpdu"][k] - o["dpdu"][k]).max() <= 1e-3 and np.abs(g["dpdv"][k] - o["dpdv"][k]).max() <= 1e-3
+    cam = make_camera((0.5, 1.6, 4.5), (0.2, 0.8, 0), fov=45, width=48, height=32)
+    for mode in (_ffi.SHADING_PATH, _ffi.SHADING_LEGACY):
+        rp = render_params(spp_min=4, max_bounces=3, shading_mode=mode)
+        gi, _ = gs.render_samples(cam, rp)
+        oi = osc.render_samples(cam, rp)
+        assert agree(gi, oi, 2e-3) >= 0.99
+
+
+@pytest.mark.parametrize("seed", [5, 8, 12, 28, 32, 33, 36, 37, 39, 61, 77, 101, 150, 199])
+def test_random_scene(rtx, seed):
+    sd, cam, rng = rand_scene(seed)
+    gs, osc = rtx.Scene(sd), OracleScene(sd)
+    for mode in (_ffi.SHADING_PATH, _ffi.SHADING_LEGACY):
+        rp = render_params(spp_min=4, max_bounces=int(rng.choice([1, 3, 8])), seed=seed * 7919 + 1, shading_mode=mode)
+        g, _ = gs.render_samples(cam, rp)
+        o = osc.render_samples(cam, rp)
+        assert np.isfinite(g).all() or not np.isfinite(o).all()
+        assert agree(g, o, 2e-3) >= 0.98, (seed, mode)
+        assert (np.abs(g[..., 3] - o[..., 3]) <= 1e-5 * (1 + np.abs(o[..., 3]))).mean() >= 0.995

@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the HIP path against the oracle: random small scenes (triangle soups, boxes, analytic spheres and
+planes under random affine transforms; Blinn / Phong / microfacet materials with random reflection, refraction,
+absorption, emission, textures and bump maps; 0..8 point and sphere lights; thin-lens cameras), rendered through the C
+ABI and through oracle/liboracle.so with the same parameters, per-sample radiance compared.
+
+    python tools/fuzz_parity.py [--seeds 0:40] [--mode path|legacy|both] [--photons]
+
+Prints one line per scene and exits non-zero if a scene falls below --min-agree. TEST INFRASTRUCTURE (uses the oracle).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import raytracer_amd as rtx  # noqa: E402
+from raytracer_amd import _ffi  # noqa: E402
+from raytracer_amd.scene import Light, Material, Mesh, SceneData, TexMap, make_camera, render_params  # noqa: E402
+from tests.oracle_ffi import OraclePhotons, OracleScene  # noqa: E402
+
+
+def rand_xform(rng, scale=1.0, spread=2.0, uniform=False):
+    A = rng.normal(size=(3, 3))
+    Q, _ = np.linalg.qr(A)
+    s = rng.uniform(0.3, 1.2, 3) * scale
+    if uniform:
+        s[:] = s[0]
+    M = Q @ np.diag(s)
+    if rng.random() < 0.3:
+        M[:, 0] = -M[:, 0]                                   # mirrored instance: flips the winding
+    t = rng.uniform(-spread, spread, 3)
+    t[1] = abs(t[1]) * 0.6
+    return np.concatenate([M, t[:, None]], axis=1).astype(np.float32).reshape(12)
+
+
+def box_mesh(rng, material, xform):
+    c = np.array([[i & 1, (i >> 1) & 1, (i >> 2) & 1] for i in range(8)], np.float32) * 2 - 1
+    f = [[0, 2, 1], [1, 2, 3], [4, 5, 6], [5, 7, 6], [0, 1, 4], [1, 5, 4], [2, 6, 3], [3, 6, 7], [0, 4, 2], [2, 4, 6], [1, 3, 5], [3, 7, 5]]
+    vt = np.concatenate([c[:, :2] * 0.5 + 0.5, np.zeros((8, 1), np.float32)], axis=1).astype(np.float32)
+    return Mesh(c, f, vt=vt, xform=xform, material=material)
+
+
+def soup_mesh(rng, material, n, xform):
+    ctr = rng.uniform(-1, 1, (n, 1, 3))
+    v = (ctr + rng.normal(scale=0.35, size=(n, 3, 3))).reshape(-1, 3).astype(np.float32)
+    f = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    vn = None
+    if rng.random() < 0.5:                                   # smooth (and deliberately not unit-length) normals
+        vn = rng.normal(size=(3 * n, 3)).astype(np.float32)
+    vt = rng.uniform(0, 1, (3 * n, 3)).astype(np.float32) if rng.random() < 0.7 else None
+    return Mesh(v, f, vn=vn, vt=vt, xform=xform, material=material)
+
+
+def rand_material(rng, n_tex):
+    kind = rng.choice(["diffuse", "glossy", "mirror", "glass", "emissive", "micro"], p=[0.3, 0.2, 0.12, 0.2, 0.06, 0.12])
+    tex = lambda p=0.35: int(rng.integers(0, n_tex)) if (n_tex and rng.random() < p) else -1
+    c = lambda lo, hi: tuple(rng.uniform(lo, hi, 3))
+    mtype = int(rng.choice([_ffi.MTL_BLINN, _ffi.MTL_PHONG]))
+    if kind == "diffuse":
+        return Material(type=mtype, diffuse=c(0.2, 0.9), specular=c(0, 0.3), glossiness=float(rng.uniform(5, 80)), diffuse_tex=tex(0.5),
+                        bump_tex=tex(0.3), bump_scale=float(rng.uniform(0.2, 2.0)))
+    if kind == "glossy":
+        return Material(type=mtype, diffuse=c(0.05, 0.5), specular=c(0.3, 0.9), glossiness=float(rng.uniform(20, 2000)), specular_tex=tex(),
+                        diffuse_tex=tex())
+    if kind == "mirror":
+        return Material(type=mtype, diffuse=c(0, 0.2), specular=c(0.2, 0.8), reflection=c(0.5, 0.95), glossiness=float(rng.choice([50.0, 1e3, 1e5])),
+                        reflection_tex=tex(0.2))
+    if kind == "glass":
+        return Material(type=mtype, diffuse=c(0, 0.1), specular=c(0.3, 0.9), refraction=c(0.6, 0.98), ior=float(rng.uniform(1.05, 2.2)),
+                        glossiness=float(rng.choice([100.0, 1e4])), absorption=c(0, 1.5), reflection=c(0, 0.3) if rng.random() < 0.3 else (0, 0, 0),
+                        refraction_tex=tex(0.15))
+    if kind == "emissive":
+        return Material(type=mtype, diffuse=c(0.1, 0.6), emission=c(0.2, 3.0), emission_tex=tex(0.4))
+    return Material(type=_ffi.MTL_MICROFACET, diffuse=c(0.1, 0.9), specular=(float(rng.uniform(0.02, 0.9)), 0, 0),
+                    reflection=(float(rng.choice([0.0, 1.0, rng.uniform(0, 1)])), 0, 0),
+                    refraction=c(0, 0.9) if rng.random() < 0.3 else (0, 0, 0), ior=float(rng.uniform(1.2, 1.9)), absorption=c(0, 1.0),
+                    diffuse_tex=tex(), specular_tex=tex(0.2), reflection_tex=tex(0.2), bump_tex=tex(0.2))
+
+
+def rand_scene(seed):
+    rng = np.random.default_rng(seed)
+    sd = SceneData()
+    n_tex = int(rng.integers(0, 4))
+    for _ in range(n_tex):
+        h, w = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        if rng.random() < 0.5:
+            t = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        else:
+            t = rng.uniform(0, 2.0, (h, w, 3)).astype(np.float32)
+        sd.texmaps.append(TexMap(t, xform=rand_xform(rng, 2.0, 0.5) if rng.random() < 0.4 else None))
+    sd.materials = [rand_material(rng, n_tex) for _ in range(int(rng.integers(1, 7)))]
+    nm = len(sd.materials)
+    mat = lambda: int(rng.integers(-1 if rng.random() < 0.05 else 0, nm))
+    floor = np.array([[-5, 0, -5], [5, 0, -5], [5, 0, 5], [-5, 0, 5]], np.float32)
+    if rng.random() < 0.8:
+        sd.meshes.append(Mesh(floor, [[0, 2, 1], [0, 3, 2]], vt=(floor[:, [0, 2, 1]] * 0.1 + 0.5).astype(np.float32), material=mat()))
+    for _ in range(int(rng.integers(1, 9))):
+        k = rng.random()
+        if k < 0.3:
+            sd.meshes.append(box_mesh(rng, mat(), rand_xform(rng, 0.6)))
+        elif k < 0.55:
+            sd.meshes.append(soup_mesh(rng, mat(), int(rng.integers(1, 60)), rand_xform(rng, 0.8) if rng.random() < 0.7 else None))
+        elif k < 0.85:
+            sd.meshes.append(Mesh.sphere(xform=rand_xform(rng, 0.7, uniform=rng.random() < 0.5), material=mat()))
+        else:
+            sd.meshes.append(Mesh.plane(xform=rand_xform(rng, 2.0), material=mat()))
+    for _ in range(int(rng.choice([0, 1, 2, 3, 8], p=[0.08, 0.3, 0.3, 0.27, 0.05]))):
+        pos = rng.uniform(-4, 4, 3)
+        pos[1] = rng.uniform(1.5, 5)
+        sd.lights.append(Light(tuple(pos), tuple(rng.uniform(2, 25, 3)), size=float(rng.choice([0.0, rng.uniform(0.05, 0.8)])),
+                               attenuation=float(rng.choice([1.0, 1.0, rng.uniform(0.2, 2.0)]))))
+    sd.environment = tuple(rng.uniform(0, 0.5, 3)) if rng.random() < 0.8 else (0, 0, 0)
+    if n_tex and rng.random() < 0.4:
+        sd.environment_tex = int(rng.integers(0, n_tex))
+    if rng.random() < 0.3:
+        sd.background = tuple(rng.uniform(0, 1, 3))
+        sd.background_emission = float(rng.choice([0.0, 0.5]))
+        if n_tex and rng.random() < 0.5:
+            sd.background_tex = int(rng.integers(0, n_tex))
+    eye = rng.uniform(-1, 1, 3) + np.array([0, 1.8, 5.0])
+    cam = make_camera(tuple(eye), tuple(rng.uniform(-0.5, 0.5, 3) + np.array([0, 0.5, 0])), fov=float(rng.uniform(25, 70)),
+                      focaldist=float(rng.uniform(3, 7)), dof=float(rng.choice([0.0, rng.uniform(0.01, 0.2)])),
+                      width=int(rng.integers(8, 48)), height=int(rng.integers(8, 32)))
+    return sd, cam, rng
+
+
+def agree(g, o, tol):
+    d = np.abs(g[..., :3] - o[..., :3]).max(-1)
+    return float((d <= tol * (1 + np.abs(o[..., :3]).max(-1))).mean())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", default="0:40")
+    ap.add_argument("--mode", default="both", choices=["path", "legacy", "both"])
+    ap.add_argument("--photons", action="store_true")
+    ap.add_argument("--spp", type=int, default=4)
+    ap.add_argument("--tol", type=float, default=2e-3)
+    ap.add_argument("--min-agree", type=float, default=0.98)
+    a = ap.parse_args()
+    lo, hi = (int(x) for x in a.seeds.split(":"))
+    modes = {"path": [_ffi.SHADING_PATH], "legacy": [_ffi.SHADING_LEGACY], "both": [_ffi.SHADING_PATH, _ffi.SHADING_LEGACY]}[a.mode]
+    worst, bad = 1.0, []
+    for seed in range(lo, hi):
+        sd, cam, rng = rand_scene(seed)
+        gs, osc = rtx.Scene(sd), OracleScene(sd)
+        gp = op = None
+        if a.photons and sd.lights:
+            gp = rtx.Photons(gs, num_photons=20000, seed=seed + 1)
+            op = OraclePhotons(osc, num_photons=20000, seed=seed + 1)
+        for mode in modes:
+            rp = render_params(spp_min=a.spp, max_bounces=int(rng.choice([1, 3, 8, 64])), seed=seed * 7919 + 1, shading_mode=mode,
+                               use_photons=int(gp is not None))
+            g, st = gs.render_samples(cam, rp, gp)
+            o = osc.render_samples(cam, rp, op)
+            # primary hit distance: exact or both misses
+            dz = np.abs(g[..., 3] - o[..., 3]) <= 1e-5 * (1 + np.abs(o[..., 3]))
+            ag = agree(g, o, a.tol)
+            fin = bool(np.isfinite(g).all())
+            ofin = bool(np.isfinite(o).all())
+            worst = min(worst, ag)
+            flag = "" if (ag >= a.min_agree and dz.mean() >= 0.999 and (fin or not ofin)) else "   <-- CHECK"
+            if flag:
+                bad.append((seed, mode))
+            print(f"seed {seed:4d} mode {mode} {cam.width:3d}x{cam.height:<3d} objs {len(sd.meshes):2d} tris {sd.n_triangles:4d} lights {len(sd.lights)} "
+                  f"bounces {rp.max_bounces:2d}  agree {ag:.4f}  z {dz.mean():.4f}  finite gpu/oracle {int(fin)}/{int(ofin)}  "
+                  f"mean {g[..., :3].mean():.4f}/{o[..., :3].mean():.4f}{flag}", flush=True)
+    print(f"worst agreement {worst:.4f}; scenes to check: {bad}")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
