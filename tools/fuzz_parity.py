@@ -126,6 +126,57 @@ def rand_scene(seed):
     return sd, cam, rng
 
 
+def rand_rays(rng, n, segments=False):
+    ray_dt, _, _ = _ffi.np_dtypes()
+    r = np.zeros(n, dtype=ray_dt)
+    o = rng.uniform(-4, 4, (n, 3)).astype(np.float32)
+    o[:, 1] = np.abs(o[:, 1]) + 0.05
+    tgt = rng.uniform(-2, 2, (n, 3)).astype(np.float32)
+    tgt[:, 1] = np.abs(tgt[:, 1]) * 0.6
+    d = tgt - o
+    ln = np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    r["o"], r["d"] = o, d / ln
+    r["tmax"] = (ln[:, 0] * rng.uniform(0.3, 1.5, n)).astype(np.float32) if segments else np.float32(1e30)
+    axis = rng.random(n) < 0.05                                # a few axis-parallel directions
+    r["d"][axis] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, int(axis.sum()))] * rng.choice([-1.0, 1.0], (int(axis.sum()), 1)).astype(np.float32)
+    return r
+
+
+def api_leg(gs, osc, sd, cam, rng, seed):
+    """trace_closest / trace_visibility on random rays, and an adaptive full-frame render with a random filter."""
+    msgs = []
+    rays = rand_rays(rng, 3000)
+    side = int(rng.choice([_ffi.HIT_FRONT, _ffi.HIT_BACK, _ffi.HIT_FRONT_AND_BACK]))
+    wl = bool(rng.random() < 0.5)
+    g, o = gs.trace_closest(rays, hit_side=side, with_lights=wl), osc.trace_closest(rays, hit_side=side, with_lights=wl)
+    same = (g["obj"] == o["obj"]) & (g["face"] == o["face"]) & (g["light"] == o["light"])
+    k = same & ((o["obj"] >= 0) | (o["light"] >= 0))
+    ok_t = np.abs(g["t"][k] - o["t"][k]) <= 2e-5 * (1 + np.abs(o["t"][k]))
+    ok_f = g["front"][k] == o["front"][k]
+    ok_n = np.abs(g["N"][k] - o["N"][k]).max(-1) <= 1e-4 if k.any() else np.ones(0, bool)
+    if same.mean() < 0.995 or (k.any() and (ok_t.mean() < 0.999 or ok_f.mean() < 0.999 or ok_n.mean() < 0.995)):
+        msgs.append(f"closest side {side} lights {int(wl)}: same {same.mean():.4f} t {ok_t.mean():.4f} front {ok_f.mean():.4f} N {ok_n.mean():.4f}")
+    seg = rand_rays(rng, 3000, segments=True)
+    nrm = rng.normal(size=(3000, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    ut = bool(rng.random() < 0.7)
+    gv, ov = gs.trace_visibility(seg, nrm, use_transmittance=ut), osc.trace_visibility(seg, nrm, use_transmittance=ut)
+    okv = np.abs(gv - ov) <= 2e-3
+    if okv.mean() < 0.995:
+        msgs.append(f"visibility transmittance {int(ut)}: {okv.mean():.4f}")
+    ft = int(rng.integers(0, 4))
+    rp = render_params(spp_min=int(rng.integers(1, 4)), spp_max=int(rng.integers(4, 10)), ci_halfwidth=float(rng.choice([0.005, 0.05])),
+                       max_bounces=int(rng.choice([2, 6])), filter_type=ft, filter_radius=float(rng.choice([0.0, 0.7, 1.0, 2.5])),
+                       tile_size=int(rng.choice([4, 16])), seed=seed + 17)
+    gi, oi = gs.render(cam, rp), osc.render(cam, rp)
+    eq = (gi["samples"] == oi["samples"]).mean()
+    dl = np.abs(gi["linear"] - oi["linear"]).mean() / (np.abs(oi["linear"]).mean() + 1e-3)
+    dz = (np.abs(gi["z"] - oi["z"]) <= 1e-5 * (1 + np.abs(oi["z"]))).mean()
+    if eq < 0.97 or dl > 0.03 or dz < 0.99 or not np.isfinite(gi["linear"]).all():
+        msgs.append(f"adaptive render filter {ft}/{rp.filter_radius:.1f} spp {rp.spp_min}..{rp.spp_max}: samples equal {eq:.4f} linear diff {dl:.4f} z {dz:.4f}")
+    return msgs
+
+
 def agree(g, o, tol):
     d = np.abs(g[..., :3] - o[..., :3]).max(-1)
     return float((d <= tol * (1 + np.abs(o[..., :3]).max(-1))).mean())
@@ -136,6 +187,7 @@ def main():
     ap.add_argument("--seeds", default="0:40")
     ap.add_argument("--mode", default="both", choices=["path", "legacy", "both"])
     ap.add_argument("--photons", action="store_true")
+    ap.add_argument("--api", action="store_true", help="also trace_closest / trace_visibility on random rays and an adaptive render")
     ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--tol", type=float, default=2e-3)
     ap.add_argument("--min-agree", type=float, default=0.98)
@@ -150,6 +202,14 @@ def main():
         if a.photons and sd.lights:
             gp = rtx.Photons(gs, num_photons=20000, seed=seed + 1)
             op = OraclePhotons(osc, num_photons=20000, seed=seed + 1)
+        if a.api:
+            msgs = api_leg(gs, osc, sd, cam, rng, seed)
+            for m in msgs:
+                print(f"seed {seed:4d} api: {m}   <-- CHECK", flush=True)
+            if msgs:
+                bad.append((seed, "api"))
+            else:
+                print(f"seed {seed:4d} api ok", flush=True)
         for mode in modes:
             rp = render_params(spp_min=a.spp, max_bounces=int(rng.choice([1, 3, 8, 64])), seed=seed * 7919 + 1, shading_mode=mode,
                                use_photons=int(gp is not None))
