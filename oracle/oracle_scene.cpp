@@ -92,7 +92,11 @@ bool Mesh::intersect_triangle(const Ray& ray, Hit& hInfo, int hitSide, int faceI
     if (v < 0.0f || u + v > 1.0f) return false;
 
     const float t = dot(e2, qvec) * invDet;
-    if (t <= EPS || t >= hInfo.z) return false;
+    if (t <= EPS || t > hInfo.z) return false;
+    // objects.cpp:166 rejects t >= hInfo.z, so among faces at exactly the same t the first one tested wins: in the
+    // reference's brute-force loop that is the smaller face index; its BVH order (cyBVH) is absent. The stated tie rule
+    //  is the brute-force one, independent of the order this BVH happens to visit faces in.
+    if (t == hInfo.z && !(hInfo.face >= 0 && faceID < hInfo.face)) return false;
 
     const float w = 1.0f - u - v;
 

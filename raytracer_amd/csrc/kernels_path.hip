@@ -417,42 +417,6 @@ __global__ void film_kernel(PathPool pool, rtx_film film, const int* __restrict_
     pool.statSum2[pix] = s2;
 }
 
-// Confidence-interval test (RayCaster.cpp:848-868 / :957-975): pixels that still need samples go to the next list.
-__global__ void adaptive_kernel(PathPool pool, const int* __restrict__ pixels, uint32_t nPix, float maxHalf, int sppMax,
-                                int* __restrict__ pixelsNext, uint32_t* counter) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool refine = false;
-    int pix = -1;
-    if (i < nPix) {
-        pix = pixels ? pixels[i] : (int)i;   // no list: the whole frame
-        if (pix >= 0) {
-            const float4 s1 = pool.statSum[pix], s2 = pool.statSum2[pix];
-            const int n = __float_as_int(s1.w);
-            if (n > 1 && n < sppMax) {
-                const float fn = (float)n;
-                const float meanR = s1.x / fn, meanG = s1.y / fn, meanB = s1.z / fn;
-                const float varR = s2.x / fn - meanR * meanR;
-                const float varG = s2.y / fn - meanG * meanG;
-                const float varB = s2.z / fn - meanB * meanB;
-                float vm = fmaxf(varR, fmaxf(varG, varB));
-                if (vm < 0.0f) vm = 0.0f;
-                const float stddev = sqrtf(vm);
-                const int df = n - 1;
-                float t;
-                if (df <= 3) t = 3.182f;
-                else if (df <= 7) t = 2.365f;
-                else if (df <= 15) t = 2.131f;
-                else if (df <= 30) t = 2.042f;
-                else t = 1.96f;
-                const float half_width = t * stddev / sqrtf(fn);
-                refine = half_width > maxHalf;
-            }
-        }
-    }
-    const uint32_t q = wave_append(refine, counter);
-    if (refine) pixelsNext[q] = pix;
-}
-
 __global__ void fill_int_kernel(int* p, uint32_t n, int v) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -471,28 +435,6 @@ __global__ void stats_clear_kernel(PathPool pool, uint32_t n) {
     if (i >= n) return;
     pool.statSum[i] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(0));
     pool.statSum2[i] = make_float4(0.0f, 0.0f, 0.0f, RTX_BIG);
-}
-
-// mergeToImage + ToColor24 (RayCaster.cpp:1188-1211, 33-48); Linear2sRGB of the absent cyColor: stand-in
-// c < 0.0031308 ? 12.92 c : 1.055 c^0.41666 - 0.055
-__global__ void film_resolve_kernel(rtx_film film, uint32_t n, int srgb, float* __restrict__ linear, unsigned char* __restrict__ rgb8) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 a = reinterpret_cast<const float4*>(film.accum)[i];
-    float c[3] = {0.0f, 0.0f, 0.0f};
-    if (a.w > 0.0f) {
-        c[0] = a.x / a.w;
-        c[1] = a.y / a.w;
-        c[2] = a.z / a.w;
-    }
-    for (int k = 0; k < 3; ++k) {
-        if (linear) linear[3 * (size_t)i + k] = c[k];
-        float x = c[k];
-        if (srgb) x = x < 0.0031308f ? x * 12.92f : powf(x, 0.41666f) * 1.055f - 0.055f;
-        x = fmaxf(x, 0.0f);
-        x = fminf(x, 1.0f);
-        if (rgb8) rgb8[3 * (size_t)i + k] = (unsigned char)(x * 255.0f);
-    }
 }
 
 // ---- launch wrappers -------------------------------------------------------------------------------------------
@@ -538,12 +480,6 @@ void launch_film(const PathPool& pool, const rtx_film& film, const int* pixels, 
         hipLaunchKernelGGL(film_kernel<false>, dim3((nPix + 255) / 256), dim3(256), 0, stream, pool, film, pixels, nPix, S, W, H,
                            filterType, filterRadius, resetZ, samplesOut, sBase, sppTotal, radianceClamp, nLights, usePhotons);
 }
-void launch_adaptive(const PathPool& pool, const int* pixels, uint32_t nPix, float maxHalf, int sppMax, int* pixelsNext,
-                     uint32_t* counter, hipStream_t stream) {
-    if (!nPix) return;
-    hipLaunchKernelGGL(adaptive_kernel, dim3((nPix + 255) / 256), dim3(256), 0, stream, pool, pixels, nPix, maxHalf, sppMax,
-                       pixelsNext, counter);
-}
 void launch_fill_int(int* p, uint32_t n, int v, hipStream_t stream) {
     if (!n) return;
     hipLaunchKernelGGL(fill_int_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, n, v);
@@ -553,7 +489,4 @@ void launch_film_clear(const rtx_film& film, uint32_t n, hipStream_t stream) {
 }
 void launch_stats_clear(const PathPool& pool, uint32_t n, hipStream_t stream) {
     hipLaunchKernelGGL(stats_clear_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pool, n);
-}
-void launch_film_resolve(const rtx_film& film, uint32_t n, int srgb, float* linear, unsigned char* rgb8, hipStream_t stream) {
-    hipLaunchKernelGGL(film_resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, film, n, srgb, linear, rgb8);
 }

@@ -1,8 +1,89 @@
-// Post-processing on the finished frame: the 3x3 median filter of the reference's built-in denoiser
-// (RayTracer/Denoiser.cpp:19-81 MedianAt / MedianFilterToLinear, :93-134 ApplyMedian's 8-bit conversion).
+// What is computed from the accumulated film and pixel statistics: the confidence-interval test of the adaptive
+// sampler, the film resolve, and the 3x3 median filter of the reference's built-in denoiser (RayTracer/Denoiser.cpp:19-81
+// MedianAt / MedianFilterToLinear, :93-134 ApplyMedian's 8-bit conversion).
+// This translation unit is compiled with IEEE division and square root (kernels_path.hip is not): the variance
+// s2/n - (s1/n)^2 of a pixel whose samples are all equal must come out as exactly zero, as it does on the CPU - with a
+// 2.5-ulp quotient a constant bright pixel (a lamp clamped to 10) shows a spurious deviation above the 0.005 threshold
+// and is refined for nothing.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
+#include "pathstate.h"
+
+__device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
+    const unsigned long long mask = __ballot(pred);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total = (uint32_t)__popcll(mask);
+    uint32_t base = 0;
+    if (total) {
+        const int leader = __ffsll((long long)mask) - 1;
+        if ((int)lane == leader) base = atomicAdd(counter, total);
+        base = __shfl(base, leader);
+    }
+    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    return base + prefix;
+}
+
+
+// Confidence-interval test (RayCaster.cpp:848-868 / :957-975): pixels that still need samples go to the next list.
+__global__ void adaptive_kernel(PathPool pool, const int* __restrict__ pixels, uint32_t nPix, float maxHalf, int sppMax,
+                                int* __restrict__ pixelsNext, uint32_t* counter) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool refine = false;
+    int pix = -1;
+    if (i < nPix) {
+        pix = pixels ? pixels[i] : (int)i;   // no list: the whole frame
+        if (pix >= 0) {
+            const float4 s1 = pool.statSum[pix], s2 = pool.statSum2[pix];
+            const int n = __float_as_int(s1.w);
+            if (n > 1 && n < sppMax) {
+                const float fn = (float)n;
+                const float meanR = s1.x / fn, meanG = s1.y / fn, meanB = s1.z / fn;
+                const float varR = s2.x / fn - meanR * meanR;
+                const float varG = s2.y / fn - meanG * meanG;
+                const float varB = s2.z / fn - meanB * meanB;
+                float vm = fmaxf(varR, fmaxf(varG, varB));
+                if (vm < 0.0f) vm = 0.0f;
+                const float stddev = sqrtf(vm);
+                const int df = n - 1;
+                float t;
+                if (df <= 3) t = 3.182f;
+                else if (df <= 7) t = 2.365f;
+                else if (df <= 15) t = 2.131f;
+                else if (df <= 30) t = 2.042f;
+                else t = 1.96f;
+                const float half_width = t * stddev / sqrtf(fn);
+                refine = half_width > maxHalf;
+            }
+        }
+    }
+    const uint32_t q = wave_append(refine, counter);
+    if (refine) pixelsNext[q] = pix;
+}
+
+
+// mergeToImage + ToColor24 (RayCaster.cpp:1188-1211, 33-48); Linear2sRGB of the absent cyColor: stand-in
+// c < 0.0031308 ? 12.92 c : 1.055 c^0.41666 - 0.055
+__global__ void film_resolve_kernel(rtx_film film, uint32_t n, int srgb, float* __restrict__ linear, unsigned char* __restrict__ rgb8) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = reinterpret_cast<const float4*>(film.accum)[i];
+    float c[3] = {0.0f, 0.0f, 0.0f};
+    if (a.w > 0.0f) {
+        c[0] = a.x / a.w;
+        c[1] = a.y / a.w;
+        c[2] = a.z / a.w;
+    }
+    for (int k = 0; k < 3; ++k) {
+        if (linear) linear[3 * (size_t)i + k] = c[k];
+        float x = c[k];
+        if (srgb) x = x < 0.0031308f ? x * 12.92f : powf(x, 0.41666f) * 1.055f - 0.055f;
+        x = fmaxf(x, 0.0f);
+        x = fminf(x, 1.0f);
+        if (rgb8) rgb8[3 * (size_t)i + k] = (unsigned char)(x * 255.0f);
+    }
+}
+
 
 // median of nine by a partial selection network on registers (the reference's nth_element picks the same value)
 __device__ __forceinline__ void mnmx(float& a, float& b) {
@@ -52,4 +133,13 @@ __global__ void median3_kernel(const float* __restrict__ src, int W, int H, int 
 void launch_median3(const float* src, int W, int H, int srgb, float* linear, unsigned char* rgb8, hipStream_t stream) {
     dim3 block(64, 4), grid((W + 63) / 64, (H + 3) / 4);
     hipLaunchKernelGGL(median3_kernel, grid, block, 0, stream, src, W, H, srgb, linear, rgb8);
+}
+void launch_adaptive(const PathPool& pool, const int* pixels, uint32_t nPix, float maxHalf, int sppMax, int* pixelsNext,
+                     uint32_t* counter, hipStream_t stream) {
+    if (!nPix) return;
+    hipLaunchKernelGGL(adaptive_kernel, dim3((nPix + 255) / 256), dim3(256), 0, stream, pool, pixels, nPix, maxHalf, sppMax,
+                       pixelsNext, counter);
+}
+void launch_film_resolve(const rtx_film& film, uint32_t n, int srgb, float* linear, unsigned char* rgb8, hipStream_t stream) {
+    hipLaunchKernelGGL(film_resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, film, n, srgb, linear, rgb8);
 }

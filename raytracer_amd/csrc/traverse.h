@@ -193,12 +193,19 @@ __device__ __forceinline__ void trav_init(TravState& s, const DevScene& sc, cons
 }
 __device__ __forceinline__ bool trav_is_inner(uint32_t cur) { return (cur & RTX_LEAF_FLAG) == 0u; }
 
+// A box is entered while tnear <= tfar * (1 + 1e-5). tnear of a flat box around a triangle at distance t is t itself
+// up to the rounding of (q - ro) * (1/dir), a few ulp either way: with a narrower margin the second of two faces at
+// exactly the same t (duplicates, coplanar overlaps) is culled half of the time once the first has set best.t = t, and
+// the tie rule (smaller face id) would depend on the visiting order. Ten-odd ulp of t in extra visits cost nothing.
+#ifndef RTX_CULL_SLACK
+#define RTX_CULL_SLACK 1.00001f
+#endif
 // next subtree that can still hold a closer (or tying) hit
 __device__ __forceinline__ void trav_pop(TravState& s, TravStack& st) {
     uint32_t next = RTX_TRAV_DONE;
     while (s.sp > 0) {
         const uint2 e = st.pop(s.sp);
-        if (__uint_as_float(e.y) <= s.best.t) {
+        if (__uint_as_float(e.y) <= s.best.t * RTX_CULL_SLACK) {
             next = e.x;
             break;
         }
@@ -212,7 +219,7 @@ __device__ __forceinline__ void trav_pop(TravState& s, TravStack& st) {
 // so the near/far bytes of all four children are picked with one select per axis before they are converted (byte ->
 // float is a single v_cvt_f32_ubyteN). Axis-parallel rays (1/dir = +-inf) give +-inf on the right side of the
 // comparison; the NaN of 0 * inf (origin exactly on a plane) is dropped by fminf/fmaxf, which only makes the test
-// more conservative. The far side is widened by 2 ulp so rounding never culls a box the ray grazes (the reference's
+// more conservative. The far side is widened (RTX_CULL_SLACK) so rounding never culls a box the ray grazes (the reference's
 // scene_box.cpp:8-46 accepts tmin <= tmax inclusively as well). [An FMA form q*k + c turns axis-parallel rays into
 // inf - inf = NaN on every plane: such rays then visit the whole tree.]
 typedef float rtx_f2 __attribute__((ext_vector_type(2)));
@@ -249,7 +256,7 @@ __device__ __forceinline__ void trav_inner_step(TravState& s, const DevScene& sc
         const rtx_f2 tz = (qz - vrz) * vdz;
         const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, 0.0f));
         const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, s.best.t));
-        const bool hit = (cr[i] != RTX_EMPTY_CHILD) && (tn <= tf * 1.0000004f);
+        const bool hit = (cr[i] != RTX_EMPTY_CHILD) && (tn <= tf * RTX_CULL_SLACK);
         ct[i] = hit ? tn : __builtin_inff();
     }
     // sort the four (distance, child) pairs, nearest first (5 compare-exchanges)

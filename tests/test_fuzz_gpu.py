@@ -100,3 +100,46 @@ def test_random_scene(rtx, seed):
         assert np.isfinite(g).all() or not np.isfinite(o).all()
         assert agree(g, o, 2e-3) >= 0.98, (seed, mode)
         assert (np.abs(g[..., 3] - o[..., 3]) <= 1e-5 * (1 + np.abs(o[..., 3]))).mean() >= 0.995
+
+
+def test_constant_bright_pixels_are_not_refined(rtx):
+    """A lamp that fills the view: every sample is the clamped radiance 10, the variance is exactly zero and the
+    confidence interval test must stop at spp_min (RayCaster.cpp:848-868). A quotient that is a few ulp off makes
+    s2/n - (s1/n)^2 positive and the half width 0.01 > 0.005."""
+    sd = SceneData()
+    sd.materials = [Material()]
+    sd.meshes = [Mesh(np.array([[-9, -9, -5], [9, -9, -5], [0, 9, -5]], np.float32), [[0, 1, 2]], material=0)]
+    sd.lights = [Light((0.0, 0.0, 0.0), (3000.0, 3000.0, 3000.0), size=1.0)]
+    sd.environment = (0.3, 0.3, 0.3)
+    cam = make_camera((0, 0, 4), (0, 0, 0), fov=20, width=24, height=16)
+    gs, osc = rtx.Scene(sd), OracleScene(sd)
+    for spp_min in (3, 5, 7):
+        rp = render_params(spp_min=spp_min, spp_max=4 * spp_min, ci_halfwidth=0.005, max_bounces=4)
+        g, o = gs.render(cam, rp), osc.render(cam, rp)
+        assert (o["samples"][4:12, 8:16] == spp_min).all()           # the oracle stops there
+        assert np.array_equal(g["samples"], o["samples"])
+        assert np.abs(g["linear"] - o["linear"]).max() <= 2e-3 * 10
+
+
+def test_duplicate_faces_tie_rule(rtx):
+    """Exact duplicates inside a mesh and a second copy of the whole object: the smaller global face id wins on the
+    GPU, in the oracle's BVH walk and in its brute-force loop alike."""
+    rng = np.random.default_rng(13)
+    a = box_mesh(rng, 0, np.array([0.6, 0, 0, 0.1, 0, 0.5, 0, 0.7, 0, 0, 0.7, 0.0], np.float32))
+    a.f = np.ascontiguousarray(np.concatenate([a.f, a.f[:4], a.f[2:3]]))
+    a.face_mtl = np.arange(a.f.shape[0], dtype=np.int32)
+    b = box_mesh(rng, 1, a.xform.copy())
+    sd = SceneData()
+    sd.materials = [Material(), Material(diffuse=(0.1, 0.9, 0.1))]
+    sd.meshes = [a, b]
+    gs, osc = rtx.Scene(sd), OracleScene(sd)
+    rays = grid_rays(32)
+    for side in (_ffi.HIT_FRONT, _ffi.HIT_BACK, _ffi.HIT_FRONT_AND_BACK):
+        g = gs.trace_closest(rays, hit_side=side)
+        o = osc.trace_closest(rays, hit_side=side, use_bvh=True)
+        ob = osc.trace_closest(rays, hit_side=side, use_bvh=False)
+        assert (o["face"] == ob["face"]).all() and (o["obj"] == ob["obj"]).all()
+        same = (g["obj"] == o["obj"]) & (g["face"] == o["face"]) & (g["mtl_id"] == o["mtl_id"])
+        assert same.mean() >= 0.995
+        hit = g["obj"] >= 0
+        assert (g["obj"][hit] == 0).all() and (g["face"][hit] < 12).all()

@@ -313,3 +313,29 @@ def test_edge_cases():
     assert (deg.trace_closest(rays, _ffi.HIT_FRONT_AND_BACK)["obj"] == -1).all()
     rays["d"] = 0
     assert (deg.trace_closest(rays, _ffi.HIT_FRONT_AND_BACK)["obj"] == -1).all()
+
+
+def test_exact_ties_take_the_smaller_face_index():
+    """Faces at exactly the same t: the brute-force loop of objects.cpp:257-264 keeps the first (t >= hInfo.z rejects);
+    the BVH walk must give the same answer whatever order it visits them in."""
+    rng = np.random.default_rng(11)
+    n = 40
+    ctr = rng.uniform(-1, 1, (n, 1, 3))
+    v = (ctr + rng.normal(scale=0.4, size=(n, 3, 3))).reshape(-1, 3).astype(np.float32)
+    f = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    f = np.concatenate([f, f[:10], f[5:15]])                    # exact duplicates of faces 0..14, some of them twice
+    sd = SceneData()
+    sd.materials = [Material()]
+    sd.meshes = [Mesh(v, f, material=0)]
+    osc = OracleScene(sd)
+    ray_dt, _, _ = _ffi.np_dtypes()
+    rays = np.zeros(4000, dtype=ray_dt)
+    rays["o"] = rng.uniform(-3, 3, (4000, 3)).astype(np.float32)
+    d = rng.uniform(-1, 1, (4000, 3)).astype(np.float32) - rays["o"]
+    rays["d"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays["tmax"] = 1e30
+    for side in (_ffi.HIT_FRONT, _ffi.HIT_BACK, _ffi.HIT_FRONT_AND_BACK):
+        a = osc.trace_closest(rays, side, use_bvh=True)
+        b = osc.trace_closest(rays, side, use_bvh=False)
+        assert (a["face"] == b["face"]).all() and (a["t"] == b["t"]).all()
+        assert (a["face"] < n).all() and (a["face"][a["obj"] >= 0] < 15).sum() > 100

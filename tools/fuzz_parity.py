@@ -126,6 +126,55 @@ def rand_scene(seed):
     return sd, cam, rng
 
 
+def spice_scene(sd, cam, seed):
+    """Second-stage mutations from a stream of their own (the base scene of a seed stays what it was): separate normal /
+    texture index arrays, per-face material ids, zero-area and duplicated triangles, overlapping coplanar faces,
+    extreme material parameters, tiny textures, texture coordinates far outside [0, 1], a visible sphere light in front
+    of the camera."""
+    rng = np.random.default_rng(seed + 100003)
+    for m in sd.meshes:
+        if m.kind != _ffi.OBJ_MESH or m.nf == 0:
+            continue
+        nf = m.f.shape[0]
+        if rng.random() < 0.5:
+            m.face_mtl = rng.integers(0, 5, nf).astype(np.int32)
+        if m.vn is not None and rng.random() < 0.5:
+            m.fn = rng.integers(0, m.vn.shape[0], (nf, 3)).astype(np.int32)
+        if m.vt is not None and rng.random() < 0.5:
+            m.ft = rng.integers(0, m.vt.shape[0], (nf, 3)).astype(np.int32)
+            m.vt = (m.vt * rng.choice([1.0, 7.0, -3.0])).astype(np.float32)
+        if rng.random() < 0.4:                                   # zero-area faces and an exact duplicate of face 0
+            extra = np.array([[m.f[0, 0], m.f[0, 0], m.f[0, 1]], m.f[0], [m.f[0, 0], m.f[0, 1], m.f[0, 1]]], np.int32)
+            m.f = np.ascontiguousarray(np.concatenate([m.f, extra]))
+            for name in ("fn", "ft"):
+                a = getattr(m, name)
+                if a is not None:
+                    setattr(m, name, np.ascontiguousarray(np.concatenate([a, a[:1].repeat(3, 0)])))
+            if m.face_mtl is not None:
+                m.face_mtl = np.ascontiguousarray(np.concatenate([m.face_mtl, m.face_mtl[:1].repeat(3)]))
+    boxes = [m for m in sd.meshes if m.kind == _ffi.OBJ_MESH and m.nf == 12]
+    if boxes and rng.random() < 0.5:                             # the same box again with another material: every face ties
+        b = boxes[0]
+        sd.meshes.append(Mesh(b.v.copy(), b.f.copy(), vt=None if b.vt is None else b.vt.copy(), xform=b.xform.copy(),
+                              material=int(rng.integers(0, len(sd.materials)))))
+    for mt in sd.materials:
+        r = rng.random()
+        if r < 0.15:
+            mt.glossiness = float(rng.choice([0.0, 1.0, 1e6]))
+        elif r < 0.3:
+            mt.ior = float(rng.choice([1.0, 0.7, 3.5]))
+        elif r < 0.4:
+            mt.absorption = (0.0, 0.0, 0.0)
+        elif r < 0.5 and mt.type != _ffi.MTL_MICROFACET:
+            mt.reflection = tuple(rng.uniform(0.3, 0.6, 3))
+            mt.refraction = tuple(rng.uniform(0.3, 0.6, 3))
+    if sd.texmaps and rng.random() < 0.5:
+        sd.texmaps[0] = TexMap(rng.integers(0, 256, (1, 1, 3)).astype(np.uint8))
+    if rng.random() < 0.5:
+        sd.lights = sd.lights[:7] + [Light((float(rng.uniform(-0.5, 0.5)), 1.2, 2.0), tuple(rng.uniform(5, 20, 3)), size=float(rng.uniform(0.2, 0.5)))]
+    return sd, cam
+
+
 def rand_rays(rng, n, segments=False):
     ray_dt, _, _ = _ffi.np_dtypes()
     r = np.zeros(n, dtype=ray_dt)
@@ -149,13 +198,17 @@ def api_leg(gs, osc, sd, cam, rng, seed):
     side = int(rng.choice([_ffi.HIT_FRONT, _ffi.HIT_BACK, _ffi.HIT_FRONT_AND_BACK]))
     wl = bool(rng.random() < 0.5)
     g, o = gs.trace_closest(rays, hit_side=side, with_lights=wl), osc.trace_closest(rays, hit_side=side, with_lights=wl)
-    same = (g["obj"] == o["obj"]) & (g["face"] == o["face"]) & (g["light"] == o["light"])
+    same = (g["obj"] == o["obj"]) & (g["face"] == o["face"]) & (g["light"] == o["light"]) & (g["mtl_id"] == o["mtl_id"])
     k = same & ((o["obj"] >= 0) | (o["light"] >= 0))
     ok_t = np.abs(g["t"][k] - o["t"][k]) <= 2e-5 * (1 + np.abs(o["t"][k]))
     ok_f = g["front"][k] == o["front"][k]
     ok_n = np.abs(g["N"][k] - o["N"][k]).max(-1) <= 1e-4 if k.any() else np.ones(0, bool)
     if same.mean() < 0.995 or (k.any() and (ok_t.mean() < 0.999 or ok_f.mean() < 0.999 or ok_n.mean() < 0.995)):
         msgs.append(f"closest side {side} lights {int(wl)}: same {same.mean():.4f} t {ok_t.mean():.4f} front {ok_f.mean():.4f} N {ok_n.mean():.4f}")
+    if os.environ.get("FUZZ_VERBOSE") and not same.all():
+        for i in np.nonzero(~same)[0][:8]:
+            print(f"      ray {i}: gpu obj {g['obj'][i]} face {g['face'][i]} mtl {g['mtl_id'][i]} light {g['light'][i]} t {g['t'][i]:.7f} front {g['front'][i]} | "
+                  f"oracle obj {o['obj'][i]} face {o['face'][i]} mtl {o['mtl_id'][i]} light {o['light'][i]} t {o['t'][i]:.7f} front {o['front'][i]}")
     seg = rand_rays(rng, 3000, segments=True)
     nrm = rng.normal(size=(3000, 3)).astype(np.float32)
     nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
@@ -172,6 +225,11 @@ def api_leg(gs, osc, sd, cam, rng, seed):
     eq = (gi["samples"] == oi["samples"]).mean()
     dl = np.abs(gi["linear"] - oi["linear"]).mean() / (np.abs(oi["linear"]).mean() + 1e-3)
     dz = (np.abs(gi["z"] - oi["z"]) <= 1e-5 * (1 + np.abs(oi["z"]))).mean()
+    if os.environ.get("FUZZ_VERBOSE") and (eq < 1.0 or dz < 1.0):
+        ys, xs = np.nonzero((gi["samples"] != oi["samples"]) | (np.abs(gi["z"] - oi["z"]) > 1e-5 * (1 + np.abs(oi["z"]))))
+        for y, x in list(zip(ys, xs))[:10]:
+            print(f"      pixel ({x},{y}): samples {gi['samples'][y, x]}/{oi['samples'][y, x]} z {gi['z'][y, x]:.6f}/{oi['z'][y, x]:.6f} "
+                  f"linear {gi['linear'][y, x]} / {oi['linear'][y, x]}")
     if eq < 0.97 or dl > 0.03 or dz < 0.99 or not np.isfinite(gi["linear"]).all():
         msgs.append(f"adaptive render filter {ft}/{rp.filter_radius:.1f} spp {rp.spp_min}..{rp.spp_max}: samples equal {eq:.4f} linear diff {dl:.4f} z {dz:.4f}")
     return msgs
@@ -187,6 +245,7 @@ def main():
     ap.add_argument("--seeds", default="0:40")
     ap.add_argument("--mode", default="both", choices=["path", "legacy", "both"])
     ap.add_argument("--photons", action="store_true")
+    ap.add_argument("--spice", action="store_true", help="second-stage mutations: index arrays, degenerate / duplicate faces, extreme materials")
     ap.add_argument("--api", action="store_true", help="also trace_closest / trace_visibility on random rays and an adaptive render")
     ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--tol", type=float, default=2e-3)
@@ -197,6 +256,8 @@ def main():
     worst, bad = 1.0, []
     for seed in range(lo, hi):
         sd, cam, rng = rand_scene(seed)
+        if a.spice:
+            spice_scene(sd, cam, seed)
         gs, osc = rtx.Scene(sd), OracleScene(sd)
         gp = op = None
         if a.photons and sd.lights:
