@@ -209,6 +209,26 @@ def api_leg(gs, osc, sd, cam, rng, seed):
         for i in np.nonzero(~same)[0][:8]:
             print(f"      ray {i}: gpu obj {g['obj'][i]} face {g['face'][i]} mtl {g['mtl_id'][i]} light {g['light'][i]} t {g['t'][i]:.7f} front {g['front'][i]} | "
                   f"oracle obj {o['obj'][i]} face {o['face'][i]} mtl {o['mtl_id'][i]} light {o['light'][i]} t {o['t'][i]:.7f} front {o['front'][i]}")
+    # ShadeInfoAdapter::TraceSecondaryRay of the legacy mode from a few of those hit points
+    import ctypes as C
+    hits = np.nonzero(k & (o["obj"] >= 0))[0][:12]
+    worst_sec = 1.0
+    for i in hits:
+        at = _ffi.ShadePoint()
+        at.P = (C.c_float * 3)(*[float(x) for x in o["p"][i]])
+        at.N = (C.c_float * 3)(*[float(x) for x in o["N"][i]])
+        at.obj, at.bounce, at.diffuse_depth = int(o["obj"][i]), int(rng.integers(0, 4)), int(rng.integers(0, 2))
+        at.pixel, at.sample, at.node = int(rng.integers(0, 1000)), int(rng.integers(0, 8)), int(rng.integers(0, 40))
+        dirs = rng.normal(size=(16, 3)).astype(np.float32)
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        child, rec = int(rng.integers(1, 4)), bool(rng.random() < 0.8)
+        gsec = gs.trace_secondary(at, dirs, recursive=rec, child=child, seed=seed + 5)
+        osec = osc.trace_secondary(at, dirs, recursive=rec, child=child, seed=seed + 5)
+        okc = (np.abs(gsec[:, :3] - osec[:, :3]).max(-1) <= 2e-3 * (1 + np.abs(osec[:, :3]).max(-1))).mean()
+        okd = (np.abs(gsec[:, 3] - osec[:, 3]) <= 1e-4 * (1 + np.abs(osec[:, 3]))).mean()
+        worst_sec = min(worst_sec, okc, okd)
+    if worst_sec < 0.8:
+        msgs.append(f"trace_secondary: worst call agrees on {worst_sec:.3f} of its 16 rays")
     seg = rand_rays(rng, 3000, segments=True)
     nrm = rng.normal(size=(3000, 3)).astype(np.float32)
     nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
@@ -271,6 +291,32 @@ def main():
                 bad.append((seed, "api"))
             else:
                 print(f"seed {seed:4d} api ok", flush=True)
+        if gp is not None:
+            # photon maps: stored counts, and the density estimate at the oracle's own photon positions
+            gi, oi = gp.info(), op.info()
+            msgs = []
+            for k in ("n_global", "n_caustic"):
+                if abs(gi[k] - oi[k]) > max(3, 0.005 * oi[k]):
+                    msgs.append(f"{k} {gi[k]} / {oi[k]}")
+            if abs(gi["photon_radius"] - oi["photon_radius"]) > 1e-6 or abs(gi["caustic_radius"] - oi["caustic_radius"]) > 1e-6:
+                msgs.append(f"radii {gi['photon_radius']},{gi['caustic_radius']} / {oi['photon_radius']},{oi['caustic_radius']}")
+            for which in (0, 1):
+                ph = op.download(which)
+                if len(ph) < 10:
+                    continue
+                sel = ph[:: max(1, len(ph) // 200)]
+                nn = -sel["dir"] / np.maximum(1e-9, np.linalg.norm(sel["dir"], axis=1, keepdims=True))
+                ge, oe = gp.estimate(which, sel["pos"], nn), op.estimate(which, sel["pos"], nn)
+                sc = np.abs(oe).max() + 1e-12
+                okp = (np.abs(ge - oe).max(-1) <= 0.03 * sc).mean()
+                if okp < 0.95:
+                    msgs.append(f"estimate map {which}: {okp:.3f} within 3 % of the largest ({len(sel)} probes of {len(ph)} photons)")
+            for m in msgs:
+                print(f"seed {seed:4d} photons: {m}   <-- CHECK", flush=True)
+            if msgs:
+                bad.append((seed, "photons"))
+            else:
+                print(f"seed {seed:4d} photons ok: global {gi['n_global']} caustic {gi['n_caustic']}", flush=True)
         for mode in modes:
             rp = render_params(spp_min=a.spp, max_bounces=int(rng.choice([1, 3, 8, 64])), seed=seed * 7919 + 1, shading_mode=mode,
                                use_photons=int(gp is not None))
