@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where does a fuzz scene disagree? tools/fuzz_diag.py SEED [MODE] [BOUNCES]: per primary-hit object, the fraction of
+"""Where does a fuzz scene disagree? [FUZZ_SPICE=1] tools/fuzz_diag.py SEED [MODE] [BOUNCES]: per primary-hit object, the fraction of
 samples whose radiance differs between the HIP path and the oracle, with that object's kind, transform and material.
 TEST INFRASTRUCTURE (uses the oracle)."""
 import os
@@ -12,13 +12,15 @@ import raytracer_amd as rtx  # noqa: E402
 from raytracer_amd import _ffi  # noqa: E402
 from raytracer_amd.scene import render_params  # noqa: E402
 from tests.oracle_ffi import OracleScene  # noqa: E402
-from tools.fuzz_parity import rand_scene  # noqa: E402
+from tools.fuzz_parity import rand_scene, spice_scene  # noqa: E402
 
 
 def main():
     seed = int(sys.argv[1])
     mode = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     sd, cam, rng = rand_scene(seed)
+    if os.environ.get("FUZZ_SPICE"):
+        spice_scene(sd, cam, seed)
     gs, osc = rtx.Scene(sd), OracleScene(sd)
     prim, t, front = gs.render_primary(cam, hit_side=_ffi.HIT_FRONT_AND_BACK)
     fb = sd.face_base()
