@@ -63,8 +63,11 @@ void launch_segq_identity(const SegQ& q, uint32_t n, hipStream_t stream) {
 #ifndef REFILL_MIN
 #define REFILL_MIN 16
 #endif
+#ifndef EXTEND_WAVES_PER_EU
+#define EXTEND_WAVES_PER_EU 6
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void extend_kernel(DevScene sc, const float4* __restrict__ rays, SegQ q,
+__global__ __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(EXTEND_WAVES_PER_EU))) void extend_kernel(DevScene sc, const float4* __restrict__ rays, SegQ q,
                                                             const uint32_t* __restrict__ items, int hitSide, int withLights,
                                                             float4* __restrict__ hits, uint2* spill, unsigned long long* counters,
                                                             uint32_t chunk) {

@@ -20,8 +20,10 @@
 #endif
 
 // traversal stack budget per lane: STACK_LDS entries in LDS, STACK_GLOBAL more in a global spill slab
+#ifndef STACK_LDS
 #define STACK_LDS 12
-#define STACK_GLOBAL 116
+#endif
+#define STACK_GLOBAL (128 - STACK_LDS)
 #define TRAV_BLOCK 256
 
 // child reference: inner node -> node index; leaf -> LEAF_FLAG | (firstTri << 3) | (count - 1)
