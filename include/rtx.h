@@ -79,7 +79,10 @@ typedef struct {
     const int* face_mtl;           /* nf per-face GetMaterialIndex, optional (objects.cpp:236) */
     int nf;
     float xform[12];               /* object->world 3x4 row-major (accumulated Node transforms; identity for
-                                      every object of assets/cerealBar.xml:5-51)             */
+                                      every object of assets/cerealBar.xml:5-51). Must be finite. A mirroring
+                                      transform (det < 0) keeps the object's own facing: front/back, GN and
+                                      rtx_hit.bu/bv follow the mesh's vertex order as in the reference, which
+                                      intersects in object space (IntersectNodeAdapter.h:62,93) */
     int material;                  /* index into rtx_scene_desc.materials; -1 = none         */
     int kind;                      /* RTX_OBJ_MESH (arrays above), or an analytic object in object space under
                                       xform: RTX_OBJ_SPHERE = unit sphere (objects.cpp:21-86), RTX_OBJ_PLANE = the
@@ -166,7 +169,9 @@ typedef struct {
     int index_stride;              /* the 1024 of sampleIndex=(y*W+x)*kMaxSamples+(s+1) (:784); 0 -> 1024 */
     float ci_halfwidth;            /* kMaxHalfWidth (:55)                                              */
     int filter_type;               /* g_filterType (:30)                                               */
-    float filter_radius;           /* g_filterRadius (:31); <= 0 selects FilterDefaultSupport          */
+    float filter_radius;           /* g_filterRadius (:31); <= 0 selects FilterDefaultSupport; values above
+                                      RTX_MAX_FILTER_RADIUS, NaN and unknown filter_type / shading_mode values
+                                      are refused with RTX_ERR_INVALID                                  */
     int max_bounces;               /* 64 in RayCaster.cpp:358; 1 = direct lighting only (config C2)    */
     uint64_t seed;                 /* counter-based RNG key                      */
     int tile_size;                 /* bucket edge (RayCaster.cpp:1152), 0 -> 16                        */
