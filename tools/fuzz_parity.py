@@ -245,7 +245,7 @@ def api_leg(gs, osc, sd, cam, rng, seed):
     gi, oi = gs.render(cam, rp), osc.render(cam, rp)
     eq = (gi["samples"] == oi["samples"]).mean()
     dl = np.abs(gi["linear"] - oi["linear"]).mean() / (np.abs(oi["linear"]).mean() + 1e-3)
-    dz = (np.abs(gi["z"] - oi["z"]) <= 1e-5 * (1 + np.abs(oi["z"]))).mean()
+    dz = (np.abs(gi["z"] - oi["z"]) <= 1e-4 * (1 + np.abs(oi["z"]))).mean()   # transformed meshes: t to 1e-4
     if os.environ.get("FUZZ_VERBOSE") and (eq < 1.0 or dz < 1.0):
         ys, xs = np.nonzero((gi["samples"] != oi["samples"]) | (np.abs(gi["z"] - oi["z"]) > 1e-5 * (1 + np.abs(oi["z"]))))
         for y, x in list(zip(ys, xs))[:10]:
@@ -266,6 +266,7 @@ def main():
     ap.add_argument("--seeds", default="0:40")
     ap.add_argument("--mode", default="both", choices=["path", "legacy", "both"])
     ap.add_argument("--photons", action="store_true")
+    ap.add_argument("--big", action="store_true", help="images of 160x120 and more: paths beyond the tail kernel's threshold, several waves per queue segment")
     ap.add_argument("--spice", action="store_true", help="second-stage mutations: index arrays, degenerate / duplicate faces, extreme materials")
     ap.add_argument("--api", action="store_true", help="also trace_closest / trace_visibility on random rays and an adaptive render")
     ap.add_argument("--spp", type=int, default=4)
@@ -279,6 +280,8 @@ def main():
         sd, cam, rng = rand_scene(seed)
         if a.spice:
             spice_scene(sd, cam, seed)
+        if a.big:
+            cam.width, cam.height = 160 + 8 * (seed % 7), 120 + 4 * (seed % 5)
         gs, osc = rtx.Scene(sd), OracleScene(sd)
         gp = op = None
         if a.photons and sd.lights:
@@ -324,7 +327,7 @@ def main():
             g, st = gs.render_samples(cam, rp, gp)
             o = osc.render_samples(cam, rp, op)
             # primary hit distance: exact or both misses
-            dz = np.abs(g[..., 3] - o[..., 3]) <= 1e-5 * (1 + np.abs(o[..., 3]))
+            dz = np.abs(g[..., 3] - o[..., 3]) <= 1e-4 * (1 + np.abs(o[..., 3]))
             ag = agree(g, o, a.tol)
             fin = bool(np.isfinite(g).all())
             ofin = bool(np.isfinite(o).all())
