@@ -172,6 +172,7 @@ __device__ __forceinline__ void resolve_triangle(const DevScene& sc, const RayT&
     } else {
         s.uvw = mk3(0.0f);
     }
+#ifndef RTX_NO_TRANSFORMED_FRAME   // (variant builds: cost of this branch on scenes without transformed meshes)
     if (o.flags & OBJ_TRANSFORMED) {
         // The reference builds this fallback frame in object space, around the object-space geometric normal, and
         // takes it to the world as vectors (objects.cpp:233-240, then Node::FromNodeCoords). GN = normalize(M^-T n)
@@ -188,7 +189,9 @@ __device__ __forceinline__ void resolve_triangle(const DevScene& sc, const RayT&
             s.dpdu = xf_vec3(F, tangent);
             s.dpdv = xf_vec3(F, bitangent);
         }
-    } else if (len2_3(s.dpdu) < RTX_EPS || len2_3(s.dpdv) < RTX_EPS) {
+    } else
+#endif
+    if (len2_3(s.dpdu) < RTX_EPS || len2_3(s.dpdv) < RTX_EPS) {
         f3 tangent = (fabsf(GN.x) > 0.5f) ? mk3(-GN.y, GN.x, 0.0f) : mk3(0.0f, -GN.z, GN.y);
         tangent = normalized3(tangent);
         f3 bitangent = cross3(GN, tangent);
