@@ -339,3 +339,63 @@ def test_exact_ties_take_the_smaller_face_index():
         b = osc.trace_closest(rays, side, use_bvh=False)
         assert (a["face"] == b["face"]).all() and (a["t"] == b["t"]).all()
         assert (a["face"] < n).all() and (a["face"][a["obj"] >= 0] < 15).sum() > 100
+
+
+def test_mirrored_transform_facing_and_tangent_frame():
+    """Independent pins for the oracle's transform handling (IntersectNodeAdapter.h:62,93): a closed box under a
+    mirroring transform, seen from outside, shows front faces only, with outward geometric normals; a face without
+    usable texture coordinates carries the object-space fallback frame (objects.cpp:233-240) to the world as
+    M * tangent, M * bitangent."""
+    M = np.array([[-0.7, 0.1, 0.0], [0.1, 0.8, 0.2], [0.0, -0.3, 0.6]], np.float64)
+    T = np.array([0.2, 0.9, -0.4], np.float64)
+    assert np.linalg.det(M) < 0
+    xf = np.concatenate([M, T[:, None]], 1).astype(np.float32).reshape(12)
+    c = np.array([[i & 1, (i >> 1) & 1, (i >> 2) & 1] for i in range(8)], np.float32) * 2 - 1
+    f = [[0, 2, 1], [1, 2, 3], [4, 5, 6], [5, 7, 6], [0, 1, 4], [1, 5, 4], [2, 6, 3], [3, 6, 7], [0, 4, 2], [2, 4, 6], [1, 3, 5], [3, 7, 5]]
+    sd = SceneData()
+    sd.materials = [Material()]
+    sd.meshes = [Mesh(c, f, xform=xf, material=0)]
+    osc = OracleScene(sd)
+    rng = np.random.default_rng(9)
+    ray_dt, _, _ = _ffi.np_dtypes()
+    n = 2000
+    rays = np.zeros(n, dtype=ray_dt)
+    o = rng.normal(size=(n, 3))
+    o = o / np.linalg.norm(o, axis=1, keepdims=True) * 6.0 + T
+    tgt = (M @ rng.uniform(-0.8, 0.8, (n, 3)).T).T + T                 # points inside the box
+    d = tgt - o
+    rays["o"], rays["d"], rays["tmax"] = o.astype(np.float32), (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32), 1e30
+    h = osc.trace_closest(rays, _ffi.HIT_FRONT_AND_BACK)
+    assert (h["obj"] == 0).all() and (h["front"] == 1).all()
+    centre_to_hit = h["p"].astype(np.float64) - T
+    assert (np.einsum("ij,ij->i", centre_to_hit, h["GN"].astype(np.float64)) > 0).all()      # outward
+    assert (np.einsum("ij,ij->i", rays["d"].astype(np.float64), h["GN"].astype(np.float64)) < 0).all()
+    assert (osc.trace_closest(rays, _ffi.HIT_BACK)["obj"] >= 0).all()                          # the far side of the box
+    assert np.array_equal(osc.trace_closest(rays, _ffi.HIT_FRONT)["face"], h["face"])
+    # fallback tangent frame: no texture coordinates -> tangent from the object-space normal, then through M
+    Minv = np.linalg.inv(M)
+    for i in range(0, n, 97):
+        n_obj = M.T @ h["GN"][i].astype(np.float64)
+        n_obj /= np.linalg.norm(n_obj)
+        t = np.array([-n_obj[1], n_obj[0], 0.0]) if abs(n_obj[0]) > 0.5 else np.array([0.0, -n_obj[2], n_obj[1]])
+        t /= np.linalg.norm(t)
+        b = np.cross(n_obj, t)
+        b /= np.linalg.norm(b)
+        assert np.allclose(h["dpdu"][i], M @ t, atol=2e-5) and np.allclose(h["dpdv"][i], M @ b, atol=2e-5)
+        assert np.allclose(Minv @ h["dpdu"][i].astype(np.float64), t, atol=5e-5)
+
+
+def test_fuzz_generator_is_deterministic():
+    """The regression seeds of tests/test_fuzz_gpu.py name scenes: the generator must give the same scene for the same seed."""
+    from tools.fuzz_parity import rand_scene, spice_scene
+    for seed in (5, 39, 287):
+        a, cam_a, _ = rand_scene(seed)
+        b, cam_b, _ = rand_scene(seed)
+        spice_scene(a, cam_a, seed)
+        spice_scene(b, cam_b, seed)
+        assert len(a.meshes) == len(b.meshes) and (cam_a.width, cam_a.height) == (cam_b.width, cam_b.height)
+        for ma, mb in zip(a.meshes, b.meshes):
+            assert np.array_equal(ma.v, mb.v) and np.array_equal(ma.f, mb.f) and np.array_equal(ma.xform, mb.xform) and ma.material == mb.material
+        assert [vars(m) for m in a.materials] == [vars(m) for m in b.materials]
+    sd, cam, _ = rand_scene(39)                                        # the seed that found the mirrored-transform defect
+    assert any(np.linalg.det(m.xform.reshape(3, 4)[:, :3]) < 0 for m in sd.meshes if m.kind == _ffi.OBJ_MESH)
