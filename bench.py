@@ -67,11 +67,19 @@ def main():
     if a.gpus != world and world == 1 and a.gpus > 1:
         print("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
+    # RTX_BENCH_BACKEND=gloo is for rehearsing the N > 1 code path on a box with fewer GPUs than ranks (ranks then share
+    # devices and the film reduce is staged through host memory); the measured configuration is nccl = RCCL, one GPU per rank
+    backend = os.environ.get("RTX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ra.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     sd = synth.build_scene(a.tri_scale)
     cam = synth.cerealbar_camera(a.width, a.height)
@@ -123,8 +131,9 @@ def main():
     sync()
     dt = time.perf_counter() - t0
 
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    rays = torch.tensor([float(agg["rays"])], dtype=torch.float64, device=dev)
+    sdev = dev if backend == "nccl" else torch.device("cpu")
+    tt = torch.tensor([dt], dtype=torch.float64, device=sdev)
+    rays = torch.tensor([float(agg["rays"])], dtype=torch.float64, device=sdev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
@@ -152,7 +161,7 @@ def main():
             "config": {"workload": (f"legacy shading mode: cerealbar-synth {W}x{H} {a.spp} spp, Whitted recursion depth 5" if a.legacy else
                                     f"C3: cerealbar-synth {W}x{H} {a.spp} spp path tracing max_bounces={a.max_bounces}"),
                        "triangles": info["triangles"], "bvh_nodes": info["nodes"], "tri_scale": a.tri_scale,
-                       "parallelism": f"tile-sharded x{world}, scene replicated, film reduce over RCCL"},
+                       "parallelism": f"tile-sharded x{world}, scene replicated, film reduce over " + ("RCCL" if backend == "nccl" else backend + " (rehearsal)")},
             "rays_per_frame": rays_all / a.steps,
             "image_finite": finite,
             "mean_linear": float(res["linear"].mean()),

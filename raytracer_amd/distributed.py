@@ -14,9 +14,15 @@ def reduce_film(accum, count, z, dst=0, group=None):
     """In-place reduction of the film tensors to rank `dst`: accum [n,4] and count [n] by SUM, z [n] by MIN."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    dist.reduce(accum, dst, op=dist.ReduceOp.SUM, group=group)
-    dist.reduce(count, dst, op=dist.ReduceOp.SUM, group=group)
-    dist.reduce(z, dst, op=dist.ReduceOp.MIN, group=group)
+    staged = dist.get_backend(group) == "gloo" and accum.is_cuda     # CPU tests / rehearsals: through host memory
+    for t, op in ((accum, dist.ReduceOp.SUM), (count, dist.ReduceOp.SUM), (z, dist.ReduceOp.MIN)):
+        if staged:
+            h = t.cpu()
+            dist.reduce(h, dst, op=op, group=group)
+            if dist.get_rank(group) == dst:
+                t.copy_(h)
+        else:
+            dist.reduce(t, dst, op=op, group=group)
 
 
 def photon_split(rank, world):
