@@ -451,6 +451,13 @@ __device__ __forceinline__ void lg_run(const LgScene& g, unsigned long long key,
 
 // TraceLegacy (RayCaster.cpp:579-631) for every camera sample of the pass, from the primary hits of extend_kernel.
 // Persistent grid: thread t handles queue items t, t + threads, ... (the traversal spill slab is sized for the grid).
+// The kernel is bound by the latency of one lane's chain of traversals and shading steps, not by issue slots: six
+// resident waves per SIMD (the most the LDS stacks allow) with 80 VGPR and 1.2 KB of scratch per lane run a 4 spp frame in
+// 195 ms where the compiler's own choice (221 VGPR, 2 waves) takes 285 ms; 3 / 4 / 5 waves: 234 / 211 / 206 ms.
+#ifndef LEGACY_WAVES_PER_EU
+#define LEGACY_WAVES_PER_EU 6
+#endif
+__attribute__((amdgpu_waves_per_eu(LEGACY_WAVES_PER_EU)))
 __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene sc, DevCamera cam, PathPool pool, DevPhotonMap pmGlobal,
                                                             DevPhotonMap pmCaustic, SegQ qIn, const uint32_t* __restrict__ queueIn,
                                                             uint32_t n, unsigned long long seed, int sBase, int S,
@@ -462,67 +469,134 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene sc, DevCame
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, nThreads = gridDim.x * blockDim.x;
     const LgScene g{sc, pmGlobal, pmCaustic, TravStack{&lds_stack[threadIdx.x], spill + gtid, nThreads}};
     unsigned long long rays = 0, shadows = 0;
-    for (uint32_t i = gtid; i < n; i += nThreads) {
-        const uint32_t slot = queueIn[segq_item_index(qtab, i)];
-        const float4 ra = pool.rays[2 * (size_t)slot], rb = pool.rays[2 * (size_t)slot + 1];
-        const float4 hv = pool.hits[slot];
-        const RayT ray{ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, ra.w};
-        const HitT h{hv.x, hv.y, hv.z, __float_as_int(hv.w)};
-        const uint32_t lane64 = slot & 63u, cs = slot >> 6;
-        const int pix = pixels[(cs / (uint32_t)S) * 64u + lane64];
-        const int sIdx = sBase + (int)(cs % (uint32_t)S);
-        const f3 rdir = mk3(ray.dx, ray.dy, ray.dz), rorg = mk3(ray.ox, ray.oy, ray.oz);
-        LgState st;
-        st.L = mk3(0.0f);
-        st.sp = 0;
-        st.rays = st.shadows = 0;
-        float primaryDist = RTX_BIG;
-        if (h.slot == -1) {   // :583-593
-            const f3 nd = normalized3(rdir);
-            float uEnv = 0.0f, vEnv = 0.0f;
-            dir_to_screen_uv(cam, nd, uEnv, vEnv);
-            const bool hasBackground = has_map_or_value(sc.bg, sc.bg_tex);
-            const bool hasEnvironment = has_map_or_value(sc.env, sc.env_tex);
-            const f3 backplate = hasBackground ? eval_tc(sc, sc.bg, sc.bg_tex, mk3(uEnv, vEnv, 0.0f)) : mk3(0.0f);
-            f3 envLight = mk3(0.0f);
-            if (hasEnvironment) envLight = sc.env_tex >= 0 ? ld3(sc.env) * tex_eval_env(sc, sc.env_tex, nd) : ld3(sc.env);
-            const f3 bgEmit = (hasBackground && sc.bg_emission > 0.0f) ? backplate * sc.bg_emission : mk3(0.0f);
-            st.L = (hasBackground ? backplate : envLight) + bgEmit;
-        } else {
-            SurfHit sh;
-            if (h.slot >= 0) resolve_triangle(sc, ray, h, sh);
-            else resolve_light(sc, ray, h, sh);
-            primaryDist = len3(sh.p - rorg);
-            if (sh.light >= 0) {   // :613-624
-                const DevLight& light = sc.lights[sh.light];
+    // A lane whose sample is finished takes its next one at once instead of waiting for the longest recursion tree of its
+    // wave (one tree can be 30 times another's). The primary hit enters the same code as a traced call - resolve, bump,
+    // Shade() - so the shading body exists once in the kernel; only the traversal is skipped for it.
+    LgState st;
+    st.L = mk3(0.0f);
+    st.sp = 0;
+    st.rays = st.shadows = 0;
+    bool have = false;            // this lane holds a sample
+    uint32_t slot = 0;
+    float primaryDist = RTX_BIG;
+    unsigned long long key = 0;
+    uint32_t i = gtid;
+    for (;;) {
+        LgCall c;
+        HitT h;
+        bool isRoot = false;
+        if (st.sp == 0) {
+            if (have) {
+                pool.L[slot] = make_float4(st.L.x, st.L.y, st.L.z, primaryDist);
+                rays += st.rays;
+                shadows += st.shadows;
+                have = false;
+            }
+            if (i >= n) break;
+            slot = queueIn[segq_item_index(qtab, i)];
+            i += nThreads;
+            const float4 ra = pool.rays[2 * (size_t)slot], rb = pool.rays[2 * (size_t)slot + 1];
+            const float4 hv = pool.hits[slot];
+            const RayT ray{ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, ra.w};
+            h = HitT{hv.x, hv.y, hv.z, __float_as_int(hv.w)};
+            const uint32_t lane64 = slot & 63u, cs = slot >> 6;
+            const int pix = pixels[(cs / (uint32_t)S) * 64u + lane64];
+            const int sIdx = sBase + (int)(cs % (uint32_t)S);
+            const f3 rdir = mk3(ray.dx, ray.dy, ray.dz), rorg = mk3(ray.ox, ray.oy, ray.oz);
+            key = rng_key(seed, (uint32_t)pix, (uint32_t)sIdx);
+            st.L = mk3(0.0f);
+            st.rays = st.shadows = 0;
+            primaryDist = RTX_BIG;
+            have = true;
+            if (h.slot == -1) {   // :583-593
+                const f3 nd = normalized3(rdir);
+                float uEnv = 0.0f, vEnv = 0.0f;
+                dir_to_screen_uv(cam, nd, uEnv, vEnv);
+                const bool hasBackground = has_map_or_value(sc.bg, sc.bg_tex);
+                const bool hasEnvironment = has_map_or_value(sc.env, sc.env_tex);
+                const f3 backplate = hasBackground ? eval_tc(sc, sc.bg, sc.bg_tex, mk3(uEnv, vEnv, 0.0f)) : mk3(0.0f);
+                f3 envLight = mk3(0.0f);
+                if (hasEnvironment) envLight = sc.env_tex >= 0 ? ld3(sc.env) * tex_eval_env(sc, sc.env_tex, nd) : ld3(sc.env);
+                const f3 bgEmit = (hasBackground && sc.bg_emission > 0.0f) ? backplate * sc.bg_emission : mk3(0.0f);
+                st.L = (hasBackground ? backplate : envLight) + bgEmit;
+                continue;
+            }
+            if (h.slot < -1) {    // a renderable light in front of the geometry: :613-624
+                SurfHit sl;
+                resolve_light(sc, ray, h, sl);
+                primaryDist = len3(sl.p - rorg);
+                const DevLight& light = sc.lights[sl.light];
                 st.L = ld3(light.intensity) / (PI_F * light.size * light.size);
-            } else {
-                const int mi = sc.objs[sh.obj].material;
-                f3 alb = mk3(0.0f);
-                if (mi >= 0) {
-                    const DevMaterial& m = sc.mtls[mi];
-                    apply_bump(sc, m, sh);
-                    SampCtx sx;
-                    sx.P = sh.p;
-                    sx.V = -normalized3(rdir);
-                    sx.N = sh.N;
-                    sx.GN = sh.GN;
-                    sx.uvw = sh.uvw;
-                    sx.front = sh.front;
-                    sx.key = rng_key(seed, (uint32_t)pix, (uint32_t)sIdx);
-                    sx.stream = 0u;
-                    lg_shade(g, m, sx, sh.obj, mk3(1.0f), 0, 0, st);
-                    lg_run(g, sx.key, st);
-                    alb = m.type == RTX_MTL_MICROFACET ? mk3(0.5f) : eval_tc(sc, m.kd, m.kd_tex, sx.uvw);   // GetDiffuseAlbedo :135-138
+                continue;
+            }
+            isRoot = true;
+            c.o = rorg;
+            c.d = rdir;
+            c.w = mk3(1.0f);
+            c.absorb = mk3(0.0f);
+            c.node = 0u;
+            c.bounceDepth = 0u;
+        } else {
+            c = st.stack[--st.sp];
+        }
+        const RayT r{c.o.x, c.o.y, c.o.z, c.d.x, c.d.y, c.d.z, RTX_BIG};
+        if (!isRoot) {   // TraceSecondaryRay :114-230: nearest renderable light against the closest geometry hit
+            st.rays++;
+            float bestLightT = RTX_BIG;
+            int visibleLight = -1;
+            for (int l = 0; l < sc.n_lights; ++l) {
+                const float t = lg_light_intersect(sc.lights[l], c.o, c.d);
+                if (t > 0.0f && t < bestLightT) {
+                    bestLightT = t;
+                    visibleLight = l;
                 }
-                const f3 fn = safe_normalize3(sh.GN);
-                pool.albedo[slot] = make_float4(alb.x, alb.y, alb.z, 1.0f);
-                pool.normal[slot] = make_float4(fn.x, fn.y, fn.z, 1.0f);
+            }
+            uint32_t nc = 0, tc = 0;
+            h = traverse_closest<false>(sc, r, RTX_HIT_FRONT_AND_BACK, g.st, &nc, &tc);
+            const bool hitGeom = h.slot >= 0;
+            if (visibleLight >= 0 && (!hitGeom || bestLightT < h.t)) {
+                const DevLight& light = sc.lights[visibleLight];
+                const f3 rad = clamp01_3(ld3(light.intensity) / (PI_F * light.size * light.size));
+                st.L = st.L + c.w * (rad * lg_absorption_factor(c.absorb, bestLightT));
+                continue;
+            }
+            if (!hitGeom) {
+                const f3 nd = normalized3(c.d);
+                const f3 env = sc.env_tex >= 0 ? ld3(sc.env) * tex_eval_env(sc, sc.env_tex, nd) : ld3(sc.env);
+                st.L = st.L + c.w * (env * lg_absorption_factor(c.absorb, RTX_BIG));
+                continue;
             }
         }
-        pool.L[slot] = make_float4(st.L.x, st.L.y, st.L.z, primaryDist);
-        rays += st.rays;
-        shadows += st.shadows;
+        SurfHit sh;
+        resolve_triangle(sc, r, h, sh);
+        const float hitDist = len3(sh.p - c.o);
+        if (isRoot) primaryDist = hitDist;
+        const float dist = (isRoot || !sh.front) ? 0.0f : hitDist;   // the root carries no absorption
+        const int mi = sc.objs[sh.obj].material;
+        if (isRoot) {
+            const f3 fn = safe_normalize3(sh.GN);
+            pool.normal[slot] = make_float4(fn.x, fn.y, fn.z, 1.0f);
+            if (mi < 0) pool.albedo[slot] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        }
+        if (mi < 0) continue;
+        const DevMaterial& m = sc.mtls[mi];
+        apply_bump(sc, m, sh);
+        SampCtx sx;
+        sx.P = sh.p;
+        sx.V = -normalized3(c.d);
+        sx.N = sh.N;
+        sx.GN = sh.GN;
+        sx.uvw = sh.uvw;
+        sx.front = sh.front;
+        sx.key = key;
+        sx.stream = c.node;
+        if (isRoot) {
+            const f3 alb = m.type == RTX_MTL_MICROFACET ? mk3(0.5f) : eval_tc(sc, m.kd, m.kd_tex, sx.uvw);   // GetDiffuseAlbedo :135-138
+            pool.albedo[slot] = make_float4(alb.x, alb.y, alb.z, 1.0f);
+        }
+        const int bounce = (int)(c.bounceDepth & 0xFFu);
+        const int dd = isRoot ? 0 : (int)(c.bounceDepth >> 8) + (mtl_is_photon_surface(m) ? 1 : 0);
+        lg_shade(g, m, sx, sh.obj, c.w * lg_absorption_factor(c.absorb, dist), bounce, dd, st);
     }
     atomicAdd(&pool.rayCounters[0], shadows);
     atomicAdd(&pool.rayCounters[1], rays);

@@ -158,6 +158,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
 #define SHADOW_REFILL_MIN 16
 #endif
 // useTransmittance: bit 0 = Visible() with transmittance (else VisibleSimple), bit 1 = no early exit (parity checks)
+#ifdef SHADOW_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(SHADOW_WAVES_PER_EU)))
+#endif
 __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene sc, PathPool pool, SegQ q, int useTransmittance, uint2* spill,
                                                             uint32_t chunk) {
     __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];

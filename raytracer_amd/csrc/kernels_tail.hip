@@ -16,6 +16,9 @@
 #define TAIL_REFILL_MIN 2u   // idle quads of a wave before it fetches new paths
 #endif
 template <bool MICRO>
+#ifdef TAIL_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(TAIL_WAVES_PER_EU)))
+#endif
 __global__ __launch_bounds__(TRAV_BLOCK) void tail_kernel(DevScene sc, DevCamera cam, PathPool pool, DevPhotonMap pm, SegQ qIn,
                                                           const uint32_t* __restrict__ queueIn, int bounce0, int maxBounces,
                                                           unsigned long long seed, int sBase, int S, const int* __restrict__ pixels,
