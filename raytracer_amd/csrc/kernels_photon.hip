@@ -7,6 +7,9 @@
 #include "shadow.h"
 #include "photon_gather.h"
 
+#ifdef PHOTON_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(PHOTON_WAVES_PER_EU)))
+#endif
 __global__ __launch_bounds__(TRAV_BLOCK) void photon_emit_kernel(DevScene sc, int numPhotons, int first, int stride, int maxBounces,
                                                                  unsigned long long seed, DevPhotonRec* __restrict__ globalOut,
                                                                  uint32_t globalCap, DevPhotonRec* __restrict__ causticOut,
