@@ -8,18 +8,28 @@
 // LINEAR in the colours its calls return - every use is `colour * weight` with a weight known at the call, and the
 // Beer-Lambert factor of a refraction ray (:359) needs only that ray's own hit distance - so it is evaluated here
 // without recursion: a pending call is a record {biased ray, weight of its colour in the sample, absorption, RNG node,
-// depth}; one lane per camera sample pops records from a small private stack, traces them, adds weight x (local
-// terms) to the sample and pushes the calls of the Shade() it reached. Sums are formed in a different order than the
-// recursion's (parity with the oracle is a tolerance, as for the path mode).
+// depth}; one lane per camera sample keeps such records on a small private stack, and legacy_kernel runs the lanes of a
+// wave as state machines that share their traversal and shading steps (see there). Sums are formed in a different order
+// than the recursion's (parity with the oracle is a tolerance, as for the path mode).
 //
 // Random numbers: Shade() number `node` of the tree (root 0; children 3*node+1 diffuse, +2 reflection, +3 refraction)
 // draws from the counter generator keyed (pixel, sample) x node x draw slot, identically in oracle/oracle_legacy.cpp.
 #include "shade_body.h"
 
 #define LG_MAX_BOUNCES 5        // ShadeInfoAdapter::kMaxSpecularBounces (:245)
-#define LG_STACK 12             // 3 calls at depth 0, then 2 left + 3 new per level down to depth 4: 11
+#define LG_STACK 20             // 3 calls at depth 0, then 2 left + 3 new per level down to depth 4: 11; + one queued
+                                // shadow query per light (<= 8) of the Shade() just evaluated (legacy_kernel)
+#define LG_SHADOW_CALL 0x80000000u   // LgCall::bounceDepth of a queued TraceShadowRay query
 #define LG_DIM_REFL 32          // draw slots of SampleGlossy for the reflection / refraction ray
 #define LG_DIM_REFR 34
+#ifndef LG_BATCH
+#define LG_BATCH 48u            // finished rays of a wave before it stops traversing to complete (shade) them: completion
+                                // is the long divergent part, so it pays to run it for many lanes at once (4 spp frame:
+                                // 527 / 330 / 261 / 203 ms at 1 / 8 / 16 / 32 with six waves per SIMD)
+#endif
+#ifndef LG_LEAF_WEIGHT
+#define LG_LEAF_WEIGHT 1u
+#endif
 
 struct LgCall {                 // one pending TraceSecondaryRay call
     f3 o, d;                    // biased origin, unit direction (:99-112)
@@ -138,6 +148,83 @@ __device__ __forceinline__ f3 lg_illuminate(const LgScene& g, const SampCtx& sx,
     const float vis = lg_trace_shadow(g, sx, obj, sampleDir * distC, 1.0f, S);
     const float avgVis = vis / 1.0f;
     return I * avgVis * atten;
+}
+
+// ---- the same two functions with the traversal taken out (legacy_kernel): the shadow segment becomes a queued call
+// that carries the light's whole contribution as its weight - visibility is exactly 0 or 1 - and is traced by the
+// kernel's shared traversal loop; lg_shadow_visible decides it from the closest hit as lg_trace_shadow does.
+// The record reuses LgCall: absorb.x = self-hit distance, absorb.y = blocking limit (< 0: unbounded segment),
+// node = the receiver's object, bounceDepth = LG_SHADOW_CALL.
+__device__ __forceinline__ void lg_push_shadow(const SampCtx& sx, int obj, f3 dir, float tMax, f3 w, LgState& S) {
+    if (w.x == 0.0f && w.y == 0.0f && w.z == 0.0f) return;
+    const float Llen = len3(dir);
+    if (Llen < 1e-12f) {   // TraceShadowRay returns 1 without tracing
+        S.L = S.L + w;
+        return;
+    }
+    if (S.sp >= LG_STACK) return;   // cannot happen (see LG_STACK)
+    const bool finiteSegment = tMax < RTX_BIG * 0.5f;
+    const float segLenWorld = finiteSegment ? Llen * tMax : RTX_BIG;
+    const f3 Ldir = dir / Llen;
+    const f3 N = sx.N;
+    const float nDotL = dot3(N, Ldir);
+    const float baseBias = 1e-4f;
+    const float nBias = baseBias * (1.0f + 2.0f * (1.0f - fabsf(nDotL)));
+    const float dBias = baseBias * 0.5f;
+    LgCall& c = S.stack[S.sp++];
+    c.o = sx.P + ((nDotL >= 0.0f) ? N : -N) * nBias + Ldir * dBias;
+    c.d = Ldir;
+    c.w = w;
+    c.absorb = mk3((nBias + dBias) * 6.0f, finiteSegment ? segLenWorld - nBias * 1.5f : -1.0f, 0.0f);
+    c.node = (uint32_t)obj;
+    c.bounceDepth = LG_SHADOW_CALL;
+    S.shadows++;
+}
+__device__ __forceinline__ bool lg_shadow_visible(const DevScene& sc, const LgCall& c, const HitT& h) {
+    if (h.slot < 0) return true;
+    const RayT r{c.o.x, c.o.y, c.o.z, c.d.x, c.d.y, c.d.z, RTX_BIG};
+    f3 GN;
+    bool front;
+    int hobj;
+    triangle_gn(sc, r, h.slot, h.t, GN, front, hobj);
+    const float4 b = reinterpret_cast<const float4*>(sc.tris)[(size_t)h.slot * 3 + 1];
+    f3 hp = c.o + c.d * h.t;
+    if (__float_as_uint(b.w) != 0u) {   // Sphere / Plane: the hit point comes back through the node transform
+        SurfHit sh;
+        resolve_triangle(sc, r, h, sh);
+        hp = sh.p;
+    }
+    const float dist = len3(hp - c.o);
+    if (hobj == (int)c.node && dist < c.absorb.x) return true;
+    if (c.absorb.y < 0.0f) return !(dist > 0.0f);
+    return !(dist < c.absorb.y);
+}
+// Illuminate with the shadow query queued: `per` is the weight of the light's radiance Li in the sample (Li = I * vis * atten)
+__device__ __forceinline__ void lg_illuminate_deferred(const SampCtx& sx, int obj, const DevLight& light, int l, f3 per, LgState& S) {
+    const f3 toC = ld3(light.pos) - sx.P;
+    const float distC = len3(toC);
+    if (distC < 1e-20f) return;
+    const f3 L = toC / distC;
+    float atten = 1.0f;
+    if (light.attenuation > 0.0f) atten = 1.0f / ((light.attenuation * distC) * (light.attenuation * distC));
+    const f3 w = per * (ld3(light.intensity) * atten);
+    if (light.size <= 0.0f) {
+        lg_push_shadow(sx, obj, toC, 1.0f, w, S);
+        return;
+    }
+    f3 U, V;
+    build_onb(L, U, V);
+    const float jx = sx.rnd(DIM_LIGHT0 + 2 * l), jy = sx.rnd(DIM_LIGHT0 + 2 * l + 1);
+    float h2 = 0.5f + jx;                 // Halton(1, 2)
+    h2 -= floorf(h2);
+    float h3 = (1.0f / 3.0f) * 1.0f + jy;   // Halton(1, 3)
+    h3 -= floorf(h3);
+    const float gamma = asinf(light.size / distC);
+    const float cosTheta = 1.0f - h2 * (1.0f - cosf(gamma));
+    const float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
+    const float phi = 2.0f * PI_F * h3;
+    const f3 sampleDir = normalized3(U * cosf(phi) * sinTheta + V * sinf(phi) * sinTheta + L * cosTheta);
+    lg_push_shadow(sx, obj, sampleDir * distC, 1.0f, w, S);
 }
 
 // FresnelExact (Shading_Legacy.cpp:296-318)
@@ -278,6 +365,8 @@ __device__ __forceinline__ bool lg_generate_sample(const DevScene& sc, const Dev
 
 // One Shade() (Shading_Legacy.cpp:366-514 Blinn, :517-659 Phong, :662-694 microfacet) whose result enters the sample
 // with weight w: adds w x (its own terms) to S.L and queues its TraceSecondaryRay calls.
+// DEFER: the shadow queries of the lights are queued (lg_push_shadow) instead of traced here.
+template <bool DEFER>
 __device__ __forceinline__ void lg_shade(const LgScene& g, const DevMaterial& m, const SampCtx& sx, int obj, f3 w, int bounce,
                                          int diffuseDepth, LgState& S) {
     const DevScene& sc = g.sc;
@@ -287,7 +376,7 @@ __device__ __forceinline__ void lg_shade(const LgScene& g, const DevMaterial& m,
         const f3 N = normalized3(sx.N);
         const f3 base = eval_tc(sc, m.kd, m.kd_tex, sx.uvw);
         f3 result = mk3(0.0f);
-        if (bounce == 0) {
+        if (bounce == 0 && !DEFER) {
             for (int l = 0; l < sc.n_lights; ++l) {
                 const f3 Ldir = normalized3(normalized3(ld3(sc.lights[l].pos) - sx.P));   // Illuminate's dir, then Ldir.Normalize() (:672)
                 const float NdotL = fmaxf(0.0f, dot3(N, Ldir));
@@ -302,6 +391,14 @@ __device__ __forceinline__ void lg_shade(const LgScene& g, const DevMaterial& m,
             DirInfo si;
             if (lg_generate_sample(sc, m, sx, indirDir, si)) lg_push(S, sx, indirDir, w * si.mult, mk3(0.0f), node * 3u + 1u, bounce + 1, diffuseDepth);
         }
+        if (bounce == 0 && DEFER) {   // queued last = traced first: the stack never holds the shadow queries of two Shade() calls
+            for (int l = 0; l < sc.n_lights; ++l) {
+                const f3 Ldir = normalized3(normalized3(ld3(sc.lights[l].pos) - sx.P));
+                const float NdotL = fmaxf(0.0f, dot3(N, Ldir));
+                if (!(NdotL > 0.0f)) continue;
+                lg_illuminate_deferred(sx, obj, sc.lights[l], l, w * (base * NdotL), S);
+            }
+        }
         result = result + eval_tc(sc, m.ke, m.ke_tex, sx.uvw);
         S.L = S.L + w * result;
         return;
@@ -315,9 +412,16 @@ __device__ __forceinline__ void lg_shade(const LgScene& g, const DevMaterial& m,
     const f3 kd = eval_tc(sc, m.kd, m.kd_tex, sx.uvw);
     const f3 ks = eval_tc(sc, m.ks, m.ks_tex, sx.uvw);
 
+    // reflection / refraction decide the weight of `local` (:499-507), so they come first here
+    const f3 refl = eval_tc(sc, m.kr, m.kr_tex, sx.uvw);
+    const f3 refrRaw = eval_tc(sc, m.kt, m.kt_tex, sx.uvw);
+    const bool isDielectric = max3c(refrRaw) > 1e-6f;
+    const bool spawn = (isDielectric || max3c(refl) > 1e-4f) && canBounce;
+    const f3 wLocal = (spawn && isDielectric) ? w * (mk3(1.0f) - refl) : w;
+
     // direct light (USE_PHOTON_MAP_DIRECT = false)
     f3 local = mk3(0.0f);
-    for (int l = 0; l < sc.n_lights; ++l) {
+    for (int l = 0; l < (DEFER ? 0 : sc.n_lights); ++l) {
         const DevLight& light = sc.lights[l];
         const f3 Ldir = normalized3(normalized3(ld3(light.pos) - sx.P));   // Illuminate's dir, then Ldir.Normalize() (:408)
         const float NdotL = fmaxf(0.0f, dot3(N, Ldir));
@@ -337,13 +441,6 @@ __device__ __forceinline__ void lg_shade(const LgScene& g, const DevMaterial& m,
             local = local + lightContrib;
         }
     }
-
-    // reflection / refraction decide the weight of `local` (:499-507), so they come first here
-    const f3 refl = eval_tc(sc, m.kr, m.kr_tex, sx.uvw);
-    const f3 refrRaw = eval_tc(sc, m.kt, m.kt_tex, sx.uvw);
-    const bool isDielectric = max3c(refrRaw) > 1e-6f;
-    const bool spawn = (isDielectric || max3c(refl) > 1e-4f) && canBounce;
-    const f3 wLocal = (spawn && isDielectric) ? w * (mk3(1.0f) - refl) : w;
 
     // indirect light (:419-457)
     f3 indirect = mk3(0.0f), causticTerm = mk3(0.0f);
@@ -387,6 +484,27 @@ __device__ __forceinline__ void lg_shade(const LgScene& g, const DevMaterial& m,
         lg_push(S, sx, rdir, isDielectric ? w * kr : w * refl, mk3(0.0f), node * 3u + 2u, bounce + 1, diffuseDepth);
     }
     if (pushDiffuse) lg_push(S, sx, diffDir, diffW, mk3(0.0f), node * 3u + 1u, bounce + 1, diffuseDepth);
+    if (DEFER) {
+        // direct light with the shadow queries queued: the factor of Li in `local` rides with each query. Queued last =
+        // traced first, so the stack never holds the shadow queries of two Shade() calls.
+        for (int l = 0; l < sc.n_lights; ++l) {
+            const DevLight& light = sc.lights[l];
+            const f3 Ldir = normalized3(normalized3(ld3(light.pos) - sx.P));
+            const float NdotL = fmaxf(0.0f, dot3(N, Ldir));
+            if (!(NdotL > 0.0f)) continue;
+            f3 per = (kd / PI_F) * NdotL;
+            if (!phong) {
+                const f3 H = normalized3(Ldir + V);
+                const float NdotH = fmaxf(0.0f, dot3(N, H));
+                if (NdotH > 0.0f) per = per + (ks * (alpha + 2.0f) / (8.0f * PI_F)) * powf(NdotH, alpha);
+            } else {
+                const f3 R = normalized3(2.0f * dot3(N, Ldir) * N - Ldir);
+                const float RdotV = fmaxf(0.0f, dot3(R, V));
+                if (RdotV > 0.0f) per = per + (ks * (alpha + 1.0f) / (2.0f * PI_F)) * powf(RdotV, alpha);
+            }
+            lg_illuminate_deferred(sx, obj, light, l, wLocal * per, S);
+        }
+    }
 }
 
 // TraceSecondaryRay from the biased ray on (ShadeInfoAdapter.h:114-230) for every queued call; firstDist receives the
@@ -445,17 +563,18 @@ __device__ __forceinline__ void lg_run(const LgScene& g, unsigned long long key,
         sx.stream = c.node;
         const int bounce = (int)(c.bounceDepth & 0xFFu);
         const int dd = (int)(c.bounceDepth >> 8) + (mtl_is_photon_surface(m) ? 1 : 0);
-        lg_shade(g, m, sx, sh.obj, c.w * lg_absorption_factor(c.absorb, dist), bounce, dd, S);
+        lg_shade<false>(g, m, sx, sh.obj, c.w * lg_absorption_factor(c.absorb, dist), bounce, dd, S);
     }
 }
 
 // TraceLegacy (RayCaster.cpp:579-631) for every camera sample of the pass, from the primary hits of extend_kernel.
 // Persistent grid: thread t handles queue items t, t + threads, ... (the traversal spill slab is sized for the grid).
-// The kernel is bound by the latency of one lane's chain of traversals and shading steps, not by issue slots: six
-// resident waves per SIMD (the most the LDS stacks allow) with 80 VGPR and 1.2 KB of scratch per lane run a 4 spp frame in
-// 195 ms where the compiler's own choice (221 VGPR, 2 waves) takes 285 ms; 3 / 4 / 5 waves: 234 / 211 / 206 ms.
+// Three resident waves per SIMD (168 VGPR): with the traversal state, the call in flight and the call stack live across
+// the whole loop, more waves mean more scratch traffic in the traversal steps (4 spp frame at batch 48: 157 / 125 / 138 /
+// 167 / 178 ms for 2 / 3 / 4 / 5 / 6 waves). [The earlier form of this kernel - one lane tracing each call to its end on
+// its own - was latency-bound instead and ran best at six waves: 285 ms at the compiler's 2 waves, 195 at 6.]
 #ifndef LEGACY_WAVES_PER_EU
-#define LEGACY_WAVES_PER_EU 6
+#define LEGACY_WAVES_PER_EU 3
 #endif
 __attribute__((amdgpu_waves_per_eu(LEGACY_WAVES_PER_EU)))
 __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene sc, DevCamera cam, PathPool pool, DevPhotonMap pmGlobal,
@@ -469,79 +588,127 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene sc, DevCame
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, nThreads = gridDim.x * blockDim.x;
     const LgScene g{sc, pmGlobal, pmCaustic, TravStack{&lds_stack[threadIdx.x], spill + gtid, nThreads}};
     unsigned long long rays = 0, shadows = 0;
-    // A lane whose sample is finished takes its next one at once instead of waiting for the longest recursion tree of its
-    // wave (one tree can be 30 times another's). The primary hit enters the same code as a traced call - resolve, bump,
-    // Shade() - so the shading body exists once in the kernel; only the traversal is skipped for it.
+    // Every lane is a small state machine: it holds one camera sample and its stack of pending calls (secondary rays and
+    // the shadow queries of the Shade() just evaluated), and at most one ray in flight. The wave runs ONE kind of step per
+    // iteration, as extend_kernel does: an inner-node or a leaf step for the lanes whose ray is in flight - whichever
+    // group is larger - or, once LG_BATCH lanes hold a finished ray (or nothing is in flight), the completion of those
+    // rays: a shadow query adds its light's contribution if nothing blocks it; a secondary ray (or the primary hit, which
+    // arrives traced by extend_kernel) is resolved, bump-mapped and shaded, which queues its own calls. A lane whose sample
+    // is done takes its next one at once (one recursion tree can be 30 times another's).
     LgState st;
     st.L = mk3(0.0f);
     st.sp = 0;
     st.rays = st.shadows = 0;
+    TravState ts;
+    ts.cur = RTX_TRAV_DONE;
+    ts.sp = 0;
+    TravStack tstack = g.st;
+    LgCall c;
+    c.o = c.d = c.w = c.absorb = mk3(0.0f);
+    c.node = c.bounceDepth = 0u;
+    HitT rootH{0.0f, 0.0f, 0.0f, -1};
     bool have = false;            // this lane holds a sample
+    bool inFlight = false;        // c is being traced (ts)
+    bool rootPending = false;     // c is the primary hit, waiting for its Shade()
+    bool finished = false;        // no samples left for this lane
     uint32_t slot = 0;
     float primaryDist = RTX_BIG;
     unsigned long long key = 0;
     uint32_t i = gtid;
     for (;;) {
-        LgCall c;
-        HitT h;
-        bool isRoot = false;
-        if (st.sp == 0) {
-            if (have) {
-                pool.L[slot] = make_float4(st.L.x, st.L.y, st.L.z, primaryDist);
-                rays += st.rays;
-                shadows += st.shadows;
-                have = false;
+        // ---- idle lanes take their next call, or their next sample ----
+        if (!inFlight && !rootPending && !finished) {
+            if (st.sp > 0) {
+                c = st.stack[--st.sp];
+                trav_init(ts, sc, RayT{c.o.x, c.o.y, c.o.z, c.d.x, c.d.y, c.d.z, RTX_BIG});
+                inFlight = true;
+                if (c.bounceDepth != LG_SHADOW_CALL) st.rays++;
+            } else {
+                if (have) {
+                    pool.L[slot] = make_float4(st.L.x, st.L.y, st.L.z, primaryDist);
+                    rays += st.rays;
+                    shadows += st.shadows;
+                    have = false;
+                }
+                if (i >= n) {
+                    finished = true;
+                } else {
+                    slot = queueIn[segq_item_index(qtab, i)];
+                    i += nThreads;
+                    const float4 ra = pool.rays[2 * (size_t)slot], rb = pool.rays[2 * (size_t)slot + 1];
+                    const float4 hv = pool.hits[slot];
+                    const RayT ray{ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, ra.w};
+                    const HitT h{hv.x, hv.y, hv.z, __float_as_int(hv.w)};
+                    const uint32_t lane64 = slot & 63u, cs = slot >> 6;
+                    const int pix = pixels[(cs / (uint32_t)S) * 64u + lane64];
+                    const int sIdx = sBase + (int)(cs % (uint32_t)S);
+                    const f3 rdir = mk3(ray.dx, ray.dy, ray.dz), rorg = mk3(ray.ox, ray.oy, ray.oz);
+                    key = rng_key(seed, (uint32_t)pix, (uint32_t)sIdx);
+                    st.L = mk3(0.0f);
+                    st.rays = st.shadows = 0;
+                    primaryDist = RTX_BIG;
+                    have = true;
+                    if (h.slot == -1) {   // :583-593
+                        const f3 nd = normalized3(rdir);
+                        float uEnv = 0.0f, vEnv = 0.0f;
+                        dir_to_screen_uv(cam, nd, uEnv, vEnv);
+                        const bool hasBackground = has_map_or_value(sc.bg, sc.bg_tex);
+                        const bool hasEnvironment = has_map_or_value(sc.env, sc.env_tex);
+                        const f3 backplate = hasBackground ? eval_tc(sc, sc.bg, sc.bg_tex, mk3(uEnv, vEnv, 0.0f)) : mk3(0.0f);
+                        f3 envLight = mk3(0.0f);
+                        if (hasEnvironment) envLight = sc.env_tex >= 0 ? ld3(sc.env) * tex_eval_env(sc, sc.env_tex, nd) : ld3(sc.env);
+                        const f3 bgEmit = (hasBackground && sc.bg_emission > 0.0f) ? backplate * sc.bg_emission : mk3(0.0f);
+                        st.L = (hasBackground ? backplate : envLight) + bgEmit;
+                    } else if (h.slot < -1) {   // a renderable light in front of the geometry: :613-624
+                        SurfHit sl;
+                        resolve_light(sc, ray, h, sl);
+                        primaryDist = len3(sl.p - rorg);
+                        const DevLight& light = sc.lights[sl.light];
+                        st.L = ld3(light.intensity) / (PI_F * light.size * light.size);
+                    } else {
+                        rootPending = true;
+                        rootH = h;
+                        c.o = rorg;
+                        c.d = rdir;
+                        c.w = mk3(1.0f);
+                        c.absorb = mk3(0.0f);
+                        c.node = 0u;
+                        c.bounceDepth = 0u;
+                    }
+                }
             }
-            if (i >= n) break;
-            slot = queueIn[segq_item_index(qtab, i)];
-            i += nThreads;
-            const float4 ra = pool.rays[2 * (size_t)slot], rb = pool.rays[2 * (size_t)slot + 1];
-            const float4 hv = pool.hits[slot];
-            const RayT ray{ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, ra.w};
-            h = HitT{hv.x, hv.y, hv.z, __float_as_int(hv.w)};
-            const uint32_t lane64 = slot & 63u, cs = slot >> 6;
-            const int pix = pixels[(cs / (uint32_t)S) * 64u + lane64];
-            const int sIdx = sBase + (int)(cs % (uint32_t)S);
-            const f3 rdir = mk3(ray.dx, ray.dy, ray.dz), rorg = mk3(ray.ox, ray.oy, ray.oz);
-            key = rng_key(seed, (uint32_t)pix, (uint32_t)sIdx);
-            st.L = mk3(0.0f);
-            st.rays = st.shadows = 0;
-            primaryDist = RTX_BIG;
-            have = true;
-            if (h.slot == -1) {   // :583-593
-                const f3 nd = normalized3(rdir);
-                float uEnv = 0.0f, vEnv = 0.0f;
-                dir_to_screen_uv(cam, nd, uEnv, vEnv);
-                const bool hasBackground = has_map_or_value(sc.bg, sc.bg_tex);
-                const bool hasEnvironment = has_map_or_value(sc.env, sc.env_tex);
-                const f3 backplate = hasBackground ? eval_tc(sc, sc.bg, sc.bg_tex, mk3(uEnv, vEnv, 0.0f)) : mk3(0.0f);
-                f3 envLight = mk3(0.0f);
-                if (hasEnvironment) envLight = sc.env_tex >= 0 ? ld3(sc.env) * tex_eval_env(sc, sc.env_tex, nd) : ld3(sc.env);
-                const f3 bgEmit = (hasBackground && sc.bg_emission > 0.0f) ? backplate * sc.bg_emission : mk3(0.0f);
-                st.L = (hasBackground ? backplate : envLight) + bgEmit;
-                continue;
+        }
+        // ---- what the wave does this iteration ----
+        const bool travDone = inFlight && ts.cur == RTX_TRAV_DONE;
+        const bool complete = rootPending || travDone;
+        const bool atInner = inFlight && !travDone && trav_is_inner(ts.cur);
+        const bool atLeaf = inFlight && !travDone && !atInner;
+        const uint32_t nComplete = (uint32_t)__popcll(__ballot(complete));
+        const uint32_t nInner = (uint32_t)__popcll(__ballot(atInner)), nLeaf = (uint32_t)__popcll(__ballot(atLeaf));
+        if (nComplete + nInner + nLeaf == 0u) {
+            if (__ballot(!finished) == 0ull) break;
+            continue;
+        }
+        if (nComplete < LG_BATCH && nInner + nLeaf > 0u) {
+            if (nLeaf * LG_LEAF_WEIGHT >= nInner) {
+                if (atLeaf) trav_leaf_step(ts, sc, tstack, RTX_HIT_FRONT_AND_BACK);
+            } else if (atInner) {
+                trav_inner_step(ts, sc, tstack);
             }
-            if (h.slot < -1) {    // a renderable light in front of the geometry: :613-624
-                SurfHit sl;
-                resolve_light(sc, ray, h, sl);
-                primaryDist = len3(sl.p - rorg);
-                const DevLight& light = sc.lights[sl.light];
-                st.L = ld3(light.intensity) / (PI_F * light.size * light.size);
-                continue;
-            }
-            isRoot = true;
-            c.o = rorg;
-            c.d = rdir;
-            c.w = mk3(1.0f);
-            c.absorb = mk3(0.0f);
-            c.node = 0u;
-            c.bounceDepth = 0u;
-        } else {
-            c = st.stack[--st.sp];
+            continue;
+        }
+        if (!complete) continue;
+        // ---- completion of a finished ray ----
+        const bool isRoot = rootPending;
+        const HitT h = isRoot ? rootH : ts.best;
+        inFlight = false;
+        rootPending = false;
+        if (c.bounceDepth == LG_SHADOW_CALL) {
+            if (lg_shadow_visible(sc, c, h)) st.L = st.L + c.w;
+            continue;
         }
         const RayT r{c.o.x, c.o.y, c.o.z, c.d.x, c.d.y, c.d.z, RTX_BIG};
         if (!isRoot) {   // TraceSecondaryRay :114-230: nearest renderable light against the closest geometry hit
-            st.rays++;
             float bestLightT = RTX_BIG;
             int visibleLight = -1;
             for (int l = 0; l < sc.n_lights; ++l) {
@@ -551,8 +718,6 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene sc, DevCame
                     visibleLight = l;
                 }
             }
-            uint32_t nc = 0, tc = 0;
-            h = traverse_closest<false>(sc, r, RTX_HIT_FRONT_AND_BACK, g.st, &nc, &tc);
             const bool hitGeom = h.slot >= 0;
             if (visibleLight >= 0 && (!hitGeom || bestLightT < h.t)) {
                 const DevLight& light = sc.lights[visibleLight];
@@ -596,7 +761,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene sc, DevCame
         }
         const int bounce = (int)(c.bounceDepth & 0xFFu);
         const int dd = isRoot ? 0 : (int)(c.bounceDepth >> 8) + (mtl_is_photon_surface(m) ? 1 : 0);
-        lg_shade(g, m, sx, sh.obj, c.w * lg_absorption_factor(c.absorb, dist), bounce, dd, st);
+        lg_shade<true>(g, m, sx, sh.obj, c.w * lg_absorption_factor(c.absorb, dist), bounce, dd, st);
     }
     atomicAdd(&pool.rayCounters[0], shadows);
     atomicAdd(&pool.rayCounters[1], rays);
