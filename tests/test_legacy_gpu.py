@@ -145,3 +145,27 @@ def test_golden_legacy_fixture(rtx):
     at.obj, at.bounce, at.diffuse_depth, at.pixel, at.sample, at.node = -1, 1, 0, 77, 1, 1
     sec = gs.trace_secondary(at, g["dirs"], recursive=True, child=1)
     assert frac_within(sec, g["secondary"]) >= 0.995
+
+
+def test_more_samples_than_resident_lanes(rtx):
+    """A pass with more camera samples than the persistent grid has lanes (1536 blocks x 256): every lane takes several
+    samples in turn, refilling itself while its neighbours are still inside their recursion trees. The GPU renders the
+    whole frame; the oracle traces a random subset of its samples."""
+    from tests.test_stress_gpu import cam_for, room
+    sd = room(n_lights=3)
+    gs, osc = rtx.Scene(sd), OracleScene(sd)
+    W, H, spp = 352, 240, 8
+    assert W * H * spp > 1536 * 256
+    cam = cam_for(1.0, W, H)
+    rp = render_params(spp_min=spp, max_bounces=8, shading_mode=_ffi.SHADING_LEGACY)
+    g, st = gs.render_samples(cam, rp)
+    assert np.isfinite(g).all() and st["rays_primary"] == W * H * spp
+    rng = np.random.default_rng(21)
+    k = 6000
+    xys = np.stack([rng.integers(0, W, k), rng.integers(0, H, k), rng.integers(0, spp, k)], 1).astype(np.int32)
+    xys[:64] = [[x, y, s] for x, y, s in zip(range(W - 64, W), [H - 1] * 64, [spp - 1] * 64)]   # the last samples handed out
+    o = osc.trace_samples(cam, rp, xys)
+    gsub = g[xys[:, 1], xys[:, 0], xys[:, 2]]
+    d = np.abs(gsub[:, :3] - o[:, :3]).max(-1)
+    assert (d <= 1e-3 * (1 + np.abs(o[:, :3]).max(-1))).mean() >= 0.99
+    assert np.allclose(gsub[:, 3], o[:, 3], rtol=1e-5)
