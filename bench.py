@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mrays/s and s/frame of the path-traced cerealbar-synth frame (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU. Started plainly, this script spawns its N ranks itself (fresh child processes, created
+before anything here touches the GPU; rank 0's JSON line is relayed, a failing rank makes the exit code non-zero).
+Started by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / WORLD_SIZE in the
+environment) it is one of those ranks.
 
 A step is one full 1920x1080 frame at 128 spp through the hot path (ray-gen, extend, shade, shadow,
 film), config C3 of BASELINE.json, on the synthetic stand-in for assets/cerealBar.xml (the real geometry is
@@ -17,17 +22,8 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import raytracer_amd as ra  # noqa: E402
-from raytracer_amd import synth, _ffi  # noqa: E402
-from raytracer_amd.scene import render_params  # noqa: E402
-from raytracer_amd.distributed import reduce_film  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
@@ -50,7 +46,38 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` started plainly: N child processes, one per GPU, with the torch.distributed.run
+    environment. The parent makes no GPU call (no torch.cuda.*, no rtx_*): it only starts the ranks, relays rank 0's
+    JSON line and reports failure if any rank fails."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    out0 = procs[0].communicate()[0]
+    codes = [p.wait() for p in procs]
+    lines = [ln for ln in out0.splitlines() if ln.startswith('{"metric"')]
+    for ln in out0.splitlines():
+        if not ln.startswith('{"metric"'):
+            print(ln, file=sys.stderr)
+    if any(codes) or len(lines) != 1:
+        print(f"bench.py: rank exit codes {codes}, {len(lines)} result lines", file=sys.stderr)
+        sys.exit(next((c for c in codes if c), 1))
+    print(lines[0], flush=True)
+
+
 def make_film(W, H, dev):
+    import torch
+    from raytracer_amd import _ffi
     n = W * H
     t = dict(accum=torch.empty((n, 4), dtype=torch.float32, device=dev), count=torch.empty(n, dtype=torch.int32, device=dev),
              z=torch.empty(n, dtype=torch.float32, device=dev), albedo=torch.empty((n, 4), dtype=torch.float32, device=dev),
@@ -61,11 +88,20 @@ def make_film(W, H, dev):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(a)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import raytracer_amd as ra
+    from raytracer_amd import synth, _ffi
+    from raytracer_amd.scene import render_params
+    from raytracer_amd.distributed import reduce_film
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world == 1 and a.gpus > 1:
-        print("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+    if a.gpus != world:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
     # RTX_BENCH_BACKEND=gloo is for rehearsing the N > 1 code path on a box with fewer GPUs than ranks (ranks then share
     # devices and the film reduce is staged through host memory); the measured configuration is nccl = RCCL, one GPU per rank
@@ -199,6 +235,8 @@ def measured_traffic(a, world):
 
 
 def cpu_baseline(sd, cam, a):
+    from raytracer_amd import _ffi
+    from raytracer_amd.scene import render_params
     """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample of the
     same workload: every 8th 16x16 bucket in x and y at a reduced sample count."""
     from tests.oracle_ffi import OracleScene

@@ -190,7 +190,10 @@ typedef struct {
 /* Film accumulators, caller-provided DEVICE memory, all width*height, row-major y*W+x
  * (per-thread buffers of RayCaster.cpp:1168-1171). The caller zeroes accum/count and fills z with
  * RTX_BIGFLOAT (rtx_film_clear does this). Multi-GPU callers sum-reduce accum/count and min-reduce z
- * across ranks (RayCaster.cpp:1182-1212) before rtx_film_resolve. */
+ * across ranks (RayCaster.cpp:1182-1212) before rtx_film_resolve; the albedo/normal guides of a pixel are written only
+ * by the rank that owns the pixel's bucket (zero elsewhere after rtx_film_clear), so they are sum-reduced as well.
+ * The library runs on the null stream of its own HIP runtime: a caller that fills or reduces these buffers with another
+ * runtime or stream (torch, RCCL) must synchronise that work with the host before the next rtx_* call that touches them. */
 typedef struct {
     float* accum;                  /* float4 per pixel: sum(w*r), sum(w*g), sum(w*b), sum(w)          */
     int*   count;                  /* originSampleCount                                                */
@@ -379,6 +382,11 @@ int rtx_photon_set(rtx_photons* p, int which, const void* photons_dev, size_t n,
 
 /* Device address of the stored raw records (48 B each, layout above) for an RCCL all-gather by the caller. */
 void* rtx_photon_device_ptr(const rtx_photons* p, int which);
+
+/* Copies the stored raw records of set `which` (48 B each, layout above) into a caller-owned DEVICE buffer of
+ * `capacity` records: the send buffer of the all-gather (raytracer_amd/distributed.py: all_gather_photons; all workers of
+ * PhotonMapBuilder.cpp:102-146 feed one map). Synchronous. Returns the number of records copied or a negative error. */
+int64_t rtx_photon_copy_raw(const rtx_photons* p, int which, void* dst_dev, size_t capacity);
 
 /* Replaces: EstimateCaustics / PhotonMap::EstimateIrradiance<N,LINEAR> (RayCaster.cpp:143-153) for host
  * probe points: irradiance rgb per probe. */

@@ -163,6 +163,7 @@ SYMBOLS = [
     ("rtx_photons_destroy", None, [_vp]),
     ("rtx_photon_info", C.c_int, [_vp, C.POINTER(C.c_uint64), c_float_p]),
     ("rtx_photon_download", C.c_int64, [_vp, C.c_int, _vp, C.c_size_t]),
+    ("rtx_photon_copy_raw", C.c_int64, [_vp, C.c_int, _vp, C.c_size_t]),
     ("rtx_photon_set", C.c_int, [_vp, C.c_int, _vp, C.c_size_t, C.c_int]),
     ("rtx_photon_device_ptr", _vp, [_vp, C.c_int]),
     ("rtx_photon_estimate", C.c_int, [_vp, C.c_int, _vp, _vp, C.c_size_t, _vp]),

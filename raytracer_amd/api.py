@@ -220,6 +220,7 @@ class Photons:
         st = _ffi.Stats()
         _check(self.lib, self.lib.rtx_photon_build(scene.h, C.byref(p), C.byref(h), C.byref(st)))
         self.h = h
+        self.num_photons = num_photons
         self.stats = stats_dict(st)
 
     def close(self):
@@ -248,6 +249,17 @@ class Photons:
         if got < 0:
             raise RtxError(self.lib.rtx_last_error().decode())
         return out[:got]
+
+    def copy_raw(self, which, dst_ptr, capacity):
+        """rtx_photon_copy_raw: raw 48-B records of set `which` into a caller-owned device buffer; returns the count."""
+        got = self.lib.rtx_photon_copy_raw(self.h, which, dst_ptr, capacity)
+        if got < 0:
+            raise RtxError(self.lib.rtx_last_error().decode())
+        return int(got)
+
+    def set_raw(self, which, src_ptr, n, total_emitted):
+        """rtx_photon_set: replace set `which` by n raw records in device memory and rebuild its grid and scaling."""
+        _check(self.lib, self.lib.rtx_photon_set(self.h, which, src_ptr, n, int(total_emitted)))
 
     def estimate(self, which, positions, normals):
         positions = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)

@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include "kernels.h"
 #include "pathstate.h"
+#include "adaptive.h"
 
 __device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
     const unsigned long long mask = __ballot(pred);
@@ -34,27 +35,7 @@ __global__ void adaptive_kernel(PathPool pool, const int* __restrict__ pixels, u
     if (i < nPix) {
         pix = pixels ? pixels[i] : (int)i;   // no list: the whole frame
         if (pix >= 0) {
-            const float4 s1 = pool.statSum[pix], s2 = pool.statSum2[pix];
-            const int n = __float_as_int(s1.w);
-            if (n > 1 && n < sppMax) {
-                const float fn = (float)n;
-                const float meanR = s1.x / fn, meanG = s1.y / fn, meanB = s1.z / fn;
-                const float varR = s2.x / fn - meanR * meanR;
-                const float varG = s2.y / fn - meanG * meanG;
-                const float varB = s2.z / fn - meanB * meanB;
-                float vm = fmaxf(varR, fmaxf(varG, varB));
-                if (vm < 0.0f) vm = 0.0f;
-                const float stddev = sqrtf(vm);
-                const int df = n - 1;
-                float t;
-                if (df <= 3) t = 3.182f;
-                else if (df <= 7) t = 2.365f;
-                else if (df <= 15) t = 2.131f;
-                else if (df <= 30) t = 2.042f;
-                else t = 1.96f;
-                const float half_width = t * stddev / sqrtf(fn);
-                refine = half_width > maxHalf;
-            }
+            refine = ci_needs_refinement(pool.statSum[pix], pool.statSum2[pix], maxHalf, sppMax);
         }
     }
     const uint32_t q = wave_append(refine, counter);

@@ -203,6 +203,16 @@ void* rtx_photon_device_ptr(const rtx_photons* p, int which) {
     return p->set[which].raw;
 }
 
+int64_t rtx_photon_copy_raw(const rtx_photons* p, int which, void* dst_dev, size_t capacity) {
+    if (!p || which < 0 || which > 1) return rtx_fail(RTX_ERR_INVALID, "bad argument");
+    const PhotonSet& s = p->set[which];
+    const size_t n = std::min<size_t>(capacity, s.n);
+    if (!n) return 0;
+    if (!dst_dev) return rtx_fail(RTX_ERR_INVALID, "dst_dev is NULL");
+    if (hipMemcpy(dst_dev, s.raw, n * sizeof(DevPhotonRec), hipMemcpyDeviceToDevice) != hipSuccess) return rtx_fail(RTX_ERR_HIP, "copy failed");
+    return (int64_t)n;
+}
+
 int rtx_photon_set(rtx_photons* p, int which, const void* photons_dev, size_t n, int total_emitted) {
     if (!p || which < 0 || which > 1 || (n && !photons_dev)) return rtx_fail(RTX_ERR_INVALID, "bad argument");
     if (n > 0x7FFFFFFFull) return rtx_fail(RTX_ERR_TOO_LARGE, "too many photons");

@@ -10,24 +10,90 @@ import torch
 import torch.distributed as dist
 
 
-def reduce_film(accum, count, z, dst=0, group=None):
-    """In-place reduction of the film tensors to rank `dst`: accum [n,4] and count [n] by SUM, z [n] by MIN."""
+def _staged(t, group):
+    """gloo moves host memory: CUDA tensors go through the host (CPU tests, rehearsals on a box with fewer GPUs)."""
+    return dist.get_backend(group) == "gloo" and t.is_cuda
+
+
+def reduce_film(accum, count, z, dst=0, group=None, albedo=None, normal=None):
+    """In-place reduction of the film tensors to rank `dst`: accum [n,4] and count [n] by SUM, z [n] by MIN; the
+    first-hit guides albedo / normal [n,4], when given, by SUM (a pixel's guides are written only by the rank that owns
+    its bucket, zero elsewhere: include/rtx.h rtx_film).
+
+    Returns with the reduction COMPLETE on the host side: over RCCL, dist.reduce only orders the collective on torch's
+    current stream, and the next consumer of these buffers is librtx_amd (rtx_film_clear / rtx_film_resolve of the next
+    step), which runs on the null stream of its own HIP runtime and has no stream ordering with torch. Without the
+    synchronisation below the next step's clear could zero the film while the reduce still reads or writes it."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    staged = dist.get_backend(group) == "gloo" and accum.is_cuda     # CPU tests / rehearsals: through host memory
-    for t, op in ((accum, dist.ReduceOp.SUM), (count, dist.ReduceOp.SUM), (z, dist.ReduceOp.MIN)):
-        if staged:
+    jobs = [(accum, dist.ReduceOp.SUM), (count, dist.ReduceOp.SUM), (z, dist.ReduceOp.MIN)]
+    jobs += [(t, dist.ReduceOp.SUM) for t in (albedo, normal) if t is not None]
+    any_cuda = False
+    for t, op in jobs:
+        if _staged(t, group):
             h = t.cpu()
             dist.reduce(h, dst, op=op, group=group)
             if dist.get_rank(group) == dst:
                 t.copy_(h)
         else:
             dist.reduce(t, dst, op=op, group=group)
+        any_cuda = any_cuda or t.is_cuda
+    if any_cuda:
+        torch.cuda.synchronize()
 
 
 def photon_split(rank, world):
     """Photon ids of a rank: rank, rank + world, ... (PhotonMapBuilder.cpp:110 hands ids out one by one)."""
     return dict(first_photon=rank, photon_stride=world)
+
+
+def all_gather_records(local, group=None):
+    """All-gather of per-rank record arrays of different lengths. local: [n_rank, k] tensor (any n_rank >= 0, same k
+    and dtype on every rank). Returns ([sum n, k] tensor with the ranks' records in rank order, list of per-rank counts).
+    Sizes are exchanged first, then one padded all_gather moves the records (RCCL all-gathers equal-sized buffers)."""
+    world = dist.get_world_size(group)
+    staged = _staged(local, group)
+    sdev = torch.device("cpu") if (staged or not local.is_cuda) else local.device
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=sdev)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    counts = [int(x.item()) for x in sizes]
+    nmax = max(counts)
+    if nmax == 0:
+        return local[:0].clone(), counts
+    send = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=sdev)
+    send[:local.shape[0]] = local.to(sdev)
+    recv = torch.empty((world, nmax) + tuple(local.shape[1:]), dtype=local.dtype, device=sdev)
+    if sdev.type == "cuda":
+        dist.all_gather_into_tensor(recv.view((world * nmax,) + tuple(local.shape[1:])), send, group=group)
+    else:
+        dist.all_gather(list(recv.unbind(0)), send, group=group)
+    out = torch.cat([recv[r, :counts[r]] for r in range(world)], dim=0).to(local.device)
+    return out.contiguous(), counts
+
+
+def all_gather_photons(photons, group=None, device=None):
+    """Every rank has traced its share of the photon ids (Photons(..., **photon_split(rank, world))); afterwards every
+    rank holds the whole map, as in the reference, where all workers feed one map that is scaled once
+    (PhotonMapBuilder.cpp:102-146, :38-50): the raw 48-B records of both sets are all-gathered (RCCL over xGMI; gloo
+    stages through the host) and rtx_photon_set rebuilds the hash grid and the power scaling (global map: 1/emitted,
+    caustic map: 1/stored over ALL ranks) on every rank. Returns (n_global, n_caustic) of the gathered map."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        info = photons.info()
+        return info["n_global"], info["n_caustic"]
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    totals = []
+    for which, key in ((0, "n_global"), (1, "n_caustic")):
+        n_local = photons.info()[key]
+        local = torch.empty((n_local, 12), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()                      # the buffer exists before the library's own runtime writes it
+        if n_local:
+            photons.copy_raw(which, local.data_ptr(), n_local)
+        allrec, counts = all_gather_records(local, group)
+        torch.cuda.synchronize()                      # gathered records are in place before librtx_amd reads them
+        photons.set_raw(which, allrec.data_ptr() if allrec.shape[0] else None, int(allrec.shape[0]), photons.num_photons)
+        totals.append(int(allrec.shape[0]))
+    return tuple(totals)
 
 
 # ---- adaptive sampling across GPUs (SURVEY.md 8e, config C4) -----------------------------------------------------

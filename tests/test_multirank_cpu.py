@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from raytracer_amd import synth
-from raytracer_amd.distributed import reduce_film, photon_split
+from raytracer_amd.distributed import reduce_film, photon_split, all_gather_records
 from raytracer_amd.scene import render_params
 from tests.oracle_ffi import OracleScene, OraclePhotons
 
@@ -63,6 +63,50 @@ def test_two_rank_film_reduce_equals_single_rank(tmp_path):
     assert np.allclose(got["accum"], ref["accum"].reshape(n, 4), rtol=1e-5, atol=1e-6)   # float sum order only
     ph = OraclePhotons(osc, 20000, finalize=False)
     assert got["cnt"][0] == ph.info()["n_global"] and got["cnt"][1] == ph.info()["n_caustic"]
+
+
+def _gather_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    res = {}
+    # ragged photon record arrays (48-B raw records = 12 floats): different lengths per rank, an empty rank, all empty
+    for case, lens in (("ragged", (5, 3)), ("empty_rank", (0, 7)), ("all_empty", (0, 0))):
+        local = torch.rand((lens[rank], 12), generator=g)
+        allrec, counts = all_gather_records(local)
+        res[case] = allrec.numpy()
+        res[case + "_counts"] = np.array(counts)
+        res[case + "_local"] = local.numpy()
+    # film guides ride along with the reduce: each pixel written by exactly one rank
+    n = 64
+    own = (torch.arange(n) % world) == rank
+    accum = torch.rand((n, 4), generator=g)
+    count = own.to(torch.int32) * 4
+    z = torch.where(own, torch.rand(n, generator=g), torch.full((n,), 1.0e30))
+    albedo = torch.where(own[:, None], torch.rand((n, 4), generator=g), torch.zeros((n, 4)))
+    res["albedo_local"], res["accum_local"], res["z_local"] = albedo.numpy().copy(), accum.numpy().copy(), z.numpy().copy()
+    reduce_film(accum, count, z, dst=0, albedo=albedo)
+    res["albedo"], res["accum"], res["z"], res["count"] = albedo.numpy(), accum.numpy(), z.numpy(), count.numpy()
+    np.savez(out_path % rank, **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_record_all_gather_and_guide_reduce(tmp_path):
+    """distributed.all_gather_records (the transport of all_gather_photons) and reduce_film's guide buffers, world 2."""
+    out = str(tmp_path / "g%d.npz")
+    mp.spawn(_gather_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = [np.load(out % k) for k in range(2)]
+    for case in ("ragged", "empty_rank", "all_empty"):
+        want = np.concatenate([r[0][case + "_local"], r[1][case + "_local"]], 0)
+        for k in range(2):                                        # every rank holds every record, in rank order
+            assert np.array_equal(r[k][case], want)
+            assert list(r[k][case + "_counts"]) == [len(r[0][case + "_local"]), len(r[1][case + "_local"])]
+    assert np.array_equal(r[0]["albedo"], r[0]["albedo_local"] + r[1]["albedo_local"])
+    assert np.allclose(r[0]["accum"], r[0]["accum_local"] + r[1]["accum_local"])
+    assert np.array_equal(r[0]["z"], np.minimum(r[0]["z_local"], r[1]["z_local"]))
+    assert (r[0]["count"] == 4).all()
 
 
 def test_lpt_assignment_is_balanced_and_deterministic():

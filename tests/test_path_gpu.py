@@ -1,9 +1,12 @@
 """GPU parity of the light-transport path (ray-gen, extend, shade, shadow, resolve, film, adaptive rounds) against
 the CPU oracle, through the C ABI. Same sampler sequence and the same counter-based RNG on both sides.
 
-Tolerances (fp32; stated per north_star): hit distances 1e-5 relative; per-sample radiance 1e-3 * (1 + |ref|) on at
-least 99.5 % of samples (the rest are paths whose branch decisions flip on libm-level differences: powf with the
-scene's gloss 1e5 amplifies one ulp of N.H to ~1 %); per-pixel image RMSE <= 2 % of the mean radiance at equal spp.
+Tolerances (fp32; stated per north_star): hit distances 1e-5 relative; per-sample radiance within 1e-4 * (1 + |ref|)
+on at least 99.99 % of samples for direct lighting and 99.5 % for the 64-bounce path loop (measured, IEEE division on
+both sides: 99.998 % / 99.75-99.8 %, tools/parity_levels.py; the rest are paths whose branch decisions flip on the last
+bit of a libm result - the GPU's powf/expf/sinf are not glibc's: powf with the scene's gloss 1e5 amplifies one ulp of
+N.H to ~1 %, and a glass path that takes the other lobe is a different path); per-pixel image RMSE <= 2 % of the mean
+radiance at equal spp.
 """
 import numpy as np
 import pytest
@@ -25,9 +28,12 @@ def small(rtx):
     return sd, cam, rtx.Scene(sd), OracleScene(sd)
 
 
-def frac_within(g, o):
+def frac_within(g, o, tol=1e-4):
     d = np.abs(g[..., :3] - o[..., :3]).max(-1)
-    return float((d <= 1e-3 * (1 + np.abs(o[..., :3]).max(-1))).mean())
+    return float((d <= tol * (1 + np.abs(o[..., :3]).max(-1))).mean())
+
+
+BAR = {1: 0.9999, 4: 0.998, 64: 0.995}     # share of samples within 1e-4 * (1 + |ref|), by max_bounces
 
 
 @pytest.mark.parametrize("max_bounces", [1, 4, 64])
@@ -41,7 +47,8 @@ def test_per_sample_radiance(small, max_bounces):
     # primary distance (first extend + thin-lens ray generation): 1e-5 relative
     pd_ok = np.abs(g[..., 3] - o[..., 3]) <= 1e-5 * np.abs(o[..., 3])
     assert pd_ok.mean() >= 0.9999
-    assert frac_within(g, o) >= 0.995
+    assert frac_within(g, o) >= BAR[max_bounces]
+    assert frac_within(g, o, 1e-3) >= 0.998
     assert st["rays_primary"] == cam.width * cam.height * 8
     assert (g[..., :3] <= 10.0).all()                      # kRadianceClamp
 
@@ -55,7 +62,7 @@ def test_image_film_z_counts(small):
     assert rmse <= 0.02 * o["linear"].mean(), rmse
     assert np.array_equal(g["samples"], o["samples"]) and (g["samples"] == 16).all()
     assert (np.abs(g["z"] - o["z"]) <= 1e-5 * np.abs(o["z"])).mean() >= 0.9999
-    assert (np.abs(g["rgb8"].astype(int) - o["rgb8"].astype(int)) <= 2).mean() >= 0.97
+    assert (np.abs(g["rgb8"].astype(int) - o["rgb8"].astype(int)) <= 1).mean() >= 0.97
     # rays actually traced: primary and bounce counts agree with the oracle to within path-divergence noise; the GPU
     # traces no shadow ray for light samples whose BSDF contribution is exactly zero
     assert g["stats"]["rays_primary"] == o["rays"]["primary"]
@@ -140,7 +147,7 @@ def test_golden_path_fixture(rtx):
     cam = synth.cerealbar_camera(48, 27)
     gs = rtx.Scene(sd)
     s, _ = gs.render_samples(cam, render_params(spp_min=4, max_bounces=64))
-    assert frac_within(s, g["samples"]) >= 0.995
+    assert frac_within(s, g["samples"]) >= 0.995 and frac_within(s, g["samples"], 1e-3) >= 0.998
     ada = gs.render(cam, render_params(spp_min=8, spp_max=32, max_bounces=8, ci_halfwidth=0.02))
     assert (ada["samples"] == g["adaptive_samples"]).mean() >= 0.995
 
@@ -158,8 +165,8 @@ def test_error_paths(small, rtx):
 
 def test_scheduling_switches_do_not_change_results(small, monkeypatch):
     """The shadow kernel's early exit, the side stream and the tail kernel are scheduling: per-sample radiance with each
-    of them switched off. Early exit and side stream: bit-identical. Tail kernel: its shading divides exactly where
-    shade_kernel uses the 2.5-ulp form, so a few long glass paths move."""
+    of them switched off is bit-identical (shade_kernel and tail_kernel instantiate the same shading body, and every
+    translation unit is built with IEEE division and square root)."""
     sd, cam, gs, osc = small
     rp = render_params(spp_min=4, max_bounces=64)
     base, st0 = gs.render_samples(cam, rp)
@@ -175,4 +182,4 @@ def test_scheduling_switches_do_not_change_results(small, monkeypatch):
     monkeypatch.setenv("RTX_AMD_TAIL_PATHS", "0")
     loop, _ = gs.render_samples(cam, rp)
     monkeypatch.delenv("RTX_AMD_TAIL_PATHS")
-    assert frac_within(loop, base) >= 0.998
+    assert np.array_equal(loop, base)
