@@ -349,6 +349,17 @@ int rtx_render_round(rtx_scene* scene, const rtx_camera* cam, const rtx_render_p
 int64_t rtx_refine_list(const rtx_pixel_stats* stats, int width, int height, float ci_halfwidth, int spp_max, int* out_pixels,
                         size_t capacity);
 
+/* No counterpart in the reference. rtx_refine_list for callers that cannot allocate device memory: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc. Same test, same ascending order, but nothing is
+ * allocated, freed or synchronised: the kernels are enqueued on `stream` (a hipStream_t or NULL) and the results go to
+ * caller-owned DEVICE buffers: out_pixels_dev[0 .. min(count, capacity)) and *out_count_dev = count. The scratch of
+ * the ordered compaction is a static device array inside the library (about 256 KB per GPU, held until the process
+ * ends), which bounds the frame: width*height above RTX_REFINE_NOALLOC_MAX_PIXELS is refused with RTX_ERR_TOO_LARGE.
+ * All calls on one GPU share that array: calls that overlap on one GPU race (serialise them on one stream). */
+#define RTX_REFINE_NOALLOC_MAX_PIXELS (1ull << 26)
+int rtx_refine_list_noalloc(const rtx_pixel_stats* stats, int width, int height, float ci_halfwidth, int spp_max,
+                            int* out_pixels_dev, size_t capacity, uint32_t* out_count_dev, void* stream);
+
 /* Replaces: RayCaster::Stop (RayCaster.cpp:1316-1318): asks an in-flight rtx_render* call on this scene (running in
  * another thread) to stop after the current bounce; that call returns RTX_OK with the samples accumulated so far.
  * The flag is cleared when the next render call starts. Async-safe. */

@@ -155,6 +155,7 @@ SYMBOLS = [
     ("rtx_render_round", C.c_int, [_vp, C.POINTER(Camera), C.POINTER(RenderParams), _vp, C.POINTER(Film), C.POINTER(PixelStats),
                                    c_int_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)]),
     ("rtx_refine_list", C.c_int64, [C.POINTER(PixelStats), C.c_int, C.c_int, C.c_float, C.c_int, c_int_p, C.c_size_t]),
+    ("rtx_refine_list_noalloc", C.c_int, [C.POINTER(PixelStats), C.c_int, C.c_int, C.c_float, C.c_int, _vp, C.c_size_t, _vp, _vp]),
     ("rtx_cancel", C.c_int, [_vp]),
     ("rtx_render", C.c_int, [_vp, C.POINTER(Camera), C.POINTER(RenderParams), _vp, _vp, _vp, _vp, _vp,
                              C.POINTER(Stats)]),

@@ -170,6 +170,13 @@ def refine_list(pstats, width, height, ci_halfwidth, spp_max):
     return out[:n].copy()
 
 
+def refine_list_noalloc(pstats, width, height, ci_halfwidth, spp_max, out_pixels_ptr, capacity, out_count_ptr, stream=None):
+    """rtx_refine_list_noalloc: the same test with caller-owned device outputs, enqueued on `stream`; allocates nothing."""
+    lib = _ffi.load_library()
+    _check(lib, lib.rtx_refine_list_noalloc(C.byref(pstats), width, height, float(ci_halfwidth), int(spp_max), out_pixels_ptr,
+                                            capacity, out_count_ptr, stream))
+
+
 def pixel_list(width, height, tile, rank, world):
     """Pixels of the 16x16 buckets that belong to `rank` (bucket b -> rank b % world), without padding."""
     lib = _ffi.load_library()
