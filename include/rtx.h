@@ -404,6 +404,36 @@ int64_t rtx_photon_copy_raw(const rtx_photons* p, int which, void* dst_dev, size
 int rtx_photon_estimate(rtx_photons* p, int which, const float* positions, const float* normals, size_t n,
                         float* irradiance);
 
+/* ---- several GPUs, one host process ---------------------------------------------------------------------------
+ * Replaces: the worker pool of RayCaster::CastRays (RayCaster.cpp:1281-1312: nThreads workers draw 16x16 buckets) and
+ * mergeToImage (:1182-1212) across the GPUs of one node, for hosts that stay one C++ process (raytracer_amd/host/
+ * RayCaster.h selects it through SamplingConfig::devices). A group holds one member per entry of device_ids, each with
+ * its own replica of the scene in that GPU's HBM; an id may repeat (members then share the GPU: how the one-GPU tests
+ * exercise the protocol). rtx_group_render runs one host thread per member: member m traces the buckets b with
+ * b % n == m into a full-frame film on its GPU (params->rank / world are ignored); the films are then copied to member
+ * 0's GPU (hipMemcpyPeer: direct xGMI transfers from all peers at once) and merged there in member order - colour,
+ * weight, counts and guides by sum, z by min - and resolved into the host arrays (any may be NULL), as rtx_render does.
+ * Adaptive sampling runs per member on its own buckets. The one-process-per-GPU alternative (RCCL) is
+ * raytracer_amd/distributed.py. */
+#define RTX_GROUP_MAX 16
+typedef struct rtx_group rtx_group;
+int rtx_group_create(const rtx_scene_desc* desc, const int* device_ids, int n, rtx_group** out);
+void rtx_group_destroy(rtx_group* g);
+int rtx_group_size(const rtx_group* g);
+/* The scene replica / photon maps of one member (borrowed; for ray queries: rtx_set_device(its device) first). */
+rtx_scene* rtx_group_scene(rtx_group* g, int member);
+rtx_photons* rtx_group_photons(rtx_group* g, int member);
+int rtx_group_render(rtx_group* g, const rtx_camera* cam, const rtx_render_params* params, float* linear_rgb,
+                     unsigned char* rgb8, float* z, int* samples, float* albedo, float* normal, rtx_stats* stats);
+/* Replaces: PhotonMapBuilder::BuildPhotonMap with its worker threads feeding one map (PhotonMapBuilder.cpp:20-60,
+ * :102-146): member m traces the photon ids m, m + n, ...; the raw records of all members are then gathered onto every
+ * member's GPU (peer copies) and each member rebuilds its hash grid and power scaling from the whole set
+ * (params->first_photon / photon_stride are ignored). The maps stay inside the group; rtx_group_render gathers from
+ * them when params->use_photons is set. stats: rays_photon summed over members. */
+int rtx_group_photon_build(rtx_group* g, const rtx_photon_params* params, rtx_stats* stats);
+/* RayCaster::Stop for a group render in flight (async-safe). */
+int rtx_group_cancel(rtx_group* g);
+
 /* Enables per-ray node/triangle counters (instrumented traversal; slower) and zeroes them. */
 int rtx_set_counters(rtx_scene* scene, int enabled);
 

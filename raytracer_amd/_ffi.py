@@ -168,6 +168,14 @@ SYMBOLS = [
     ("rtx_photon_set", C.c_int, [_vp, C.c_int, _vp, C.c_size_t, C.c_int]),
     ("rtx_photon_device_ptr", _vp, [_vp, C.c_int]),
     ("rtx_photon_estimate", C.c_int, [_vp, C.c_int, _vp, _vp, C.c_size_t, _vp]),
+    ("rtx_group_create", C.c_int, [C.POINTER(SceneDesc), c_int_p, C.c_int, C.POINTER(_vp)]),
+    ("rtx_group_destroy", None, [_vp]),
+    ("rtx_group_size", C.c_int, [_vp]),
+    ("rtx_group_scene", _vp, [_vp, C.c_int]),
+    ("rtx_group_photons", _vp, [_vp, C.c_int]),
+    ("rtx_group_render", C.c_int, [_vp, C.POINTER(Camera), C.POINTER(RenderParams), _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(Stats)]),
+    ("rtx_group_photon_build", C.c_int, [_vp, C.POINTER(PhotonParams), C.POINTER(Stats)]),
+    ("rtx_group_cancel", C.c_int, [_vp]),
     ("rtx_set_counters", C.c_int, [_vp, C.c_int]),
     ("rtx_get_counters", C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     ("rtx_debug_validate_bvh", C.c_int, [C.POINTER(SceneDesc), C.POINTER(C.c_uint64)]),

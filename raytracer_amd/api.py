@@ -144,6 +144,65 @@ class Scene:
         return out, stats_dict(st)
 
 
+class Group:
+    """Several GPUs driven from this one process (rtx_group): one scene replica per entry of `devices` (an id may repeat),
+    buckets dealt b % n, films merged on the first member's GPU. The C++ host mirror uses the same entry points."""
+
+    def __init__(self, data: SceneData, devices):
+        self.lib = _ffi.load_library()
+        desc, keep = data.to_desc()
+        ids = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _check(self.lib, self.lib.rtx_group_create(C.byref(desc), ids, len(devices), C.byref(h)))
+        self.h = h
+        self.devices = list(devices)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rtx_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, cam, params):
+        n = cam.width * cam.height
+        linear = np.zeros((n, 3), dtype=np.float32)
+        rgb8 = np.zeros((n, 3), dtype=np.uint8)
+        z = np.zeros(n, dtype=np.float32)
+        samples = np.zeros(n, dtype=np.int32)
+        albedo = np.zeros((n, 3), dtype=np.float32)
+        normal = np.zeros((n, 3), dtype=np.float32)
+        st = _ffi.Stats()
+        _check(self.lib, self.lib.rtx_group_render(self.h, C.byref(cam), C.byref(params), linear.ctypes.data, rgb8.ctypes.data,
+                                                   z.ctypes.data, samples.ctypes.data, albedo.ctypes.data, normal.ctypes.data, C.byref(st)))
+        shape = (cam.height, cam.width)
+        return dict(linear=linear.reshape(shape + (3,)), rgb8=rgb8.reshape(shape + (3,)), z=z.reshape(shape),
+                    samples=samples.reshape(shape), albedo=albedo.reshape(shape + (3,)), normal=normal.reshape(shape + (3,)),
+                    stats=stats_dict(st))
+
+    def photon_build(self, num_photons=10_000_000, max_bounces=2, photon_radius=0.0, caustic_radius=0.0, search_count=100,
+                     seed=0x9E3779B97F4A7C15):
+        p = _ffi.PhotonParams(num_photons, max_bounces, photon_radius, caustic_radius, search_count, seed, 0, 1)
+        st = _ffi.Stats()
+        _check(self.lib, self.lib.rtx_group_photon_build(self.h, C.byref(p), C.byref(st)))
+        return stats_dict(st)
+
+    def member_photons(self, member):
+        """Photons view of one member's maps (borrowed: info / estimate / download only)."""
+        ph = Photons.__new__(Photons)
+        ph.lib = self.lib
+        h = self.lib.rtx_group_photons(self.h, member)
+        if not h:
+            raise RtxError("the group holds no photon map (photon_build first)")
+        ph.h = C.c_void_p(h)
+        ph.close = lambda: None          # the group owns the handle
+        return ph
+
+
 def stats_dict(st):
     return {k: getattr(st, k) for k, _ in _ffi.Stats._fields_}
 

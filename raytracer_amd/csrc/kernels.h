@@ -82,3 +82,5 @@ void launch_fill_int(int* p, uint32_t n, int v, hipStream_t stream);
 void launch_film_clear(const rtx_film& film, uint32_t n, hipStream_t stream);
 void launch_stats_clear(const PathPool& pool, uint32_t n, hipStream_t stream);
 void launch_film_resolve(const rtx_film& film, uint32_t n, int srgb, float* linear, unsigned char* rgb8, hipStream_t stream);
+// dst += srcs[0 .. nSrc) (accum, count, guides by sum; z by min); all buffers on the device of `stream`; nSrc < RTX_GROUP_MAX
+void launch_film_merge(const rtx_film& dst, const rtx_film* srcs, int nSrc, uint32_t n, hipStream_t stream);

@@ -111,6 +111,50 @@ __global__ void median3_kernel(const float* __restrict__ src, int W, int H, int 
     }
 }
 
+// mergeToImage across GPUs (RayCaster.cpp:1182-1212): dst += the films of the other group members, in member order
+// (a fixed order of float additions: the merged frame does not depend on which member finished first), z by min;
+// the first-hit guides of a pixel are written by one member only, so they add up as well.
+struct FilmMergeSrc {
+    rtx_film f[RTX_GROUP_MAX - 1];
+    int n;
+};
+__global__ void film_merge_kernel(rtx_film dst, FilmMergeSrc src, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 a = reinterpret_cast<float4*>(dst.accum)[i];
+    int c = dst.count[i];
+    float z = dst.z[i];
+    float4 al = dst.albedo ? reinterpret_cast<float4*>(dst.albedo)[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 nn = dst.normal ? reinterpret_cast<float4*>(dst.normal)[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int k = 0; k < src.n; ++k) {
+        const rtx_film& s = src.f[k];
+        const float4 b = reinterpret_cast<const float4*>(s.accum)[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        c += s.count[i];
+        z = fminf(z, s.z[i]);
+        if (dst.albedo && s.albedo) {
+            const float4 t = reinterpret_cast<const float4*>(s.albedo)[i];
+            al.x += t.x; al.y += t.y; al.z += t.z; al.w += t.w;
+        }
+        if (dst.normal && s.normal) {
+            const float4 t = reinterpret_cast<const float4*>(s.normal)[i];
+            nn.x += t.x; nn.y += t.y; nn.z += t.z; nn.w += t.w;
+        }
+    }
+    reinterpret_cast<float4*>(dst.accum)[i] = a;
+    dst.count[i] = c;
+    dst.z[i] = z;
+    if (dst.albedo) reinterpret_cast<float4*>(dst.albedo)[i] = al;
+    if (dst.normal) reinterpret_cast<float4*>(dst.normal)[i] = nn;
+}
+void launch_film_merge(const rtx_film& dst, const rtx_film* srcs, int nSrc, uint32_t n, hipStream_t stream) {
+    if (!n || nSrc <= 0) return;
+    FilmMergeSrc m;
+    m.n = nSrc;
+    for (int k = 0; k < nSrc; ++k) m.f[k] = srcs[k];
+    hipLaunchKernelGGL(film_merge_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dst, m, n);
+}
+
 void launch_median3(const float* src, int W, int H, int srgb, float* linear, unsigned char* rgb8, hipStream_t stream) {
     dim3 block(64, 4), grid((W + 63) / 64, (H + 3) / 4);
     hipLaunchKernelGGL(median3_kernel, grid, block, 0, stream, src, W, H, srgb, linear, rgb8);

@@ -28,13 +28,12 @@ public:
 class PhotonMapBuilder {
 public:
     PhotonMapBuilder() = default;
-    virtual ~PhotonMapBuilder() { rtx_photons_destroy(handle); }
+    virtual ~PhotonMapBuilder() { Release(); }
 
     // PhotonMapBuilder.cpp:20-60
     void BuildPhotonMap(Scene* scene) {
         if (!scene) return;
-        rtx_photons_destroy(handle);
-        handle = nullptr;
+        Release();
         photonMap.owner = causticsMap.owner = nullptr;
         rtx_photon_params p{};
         p.num_photons = numPhotons;
@@ -46,7 +45,17 @@ public:
         p.first_photon = 0;
         p.photon_stride = 1;
         std::cout << "Building photon map with " << numPhotons << " photons...\n";
-        if (rtx_photon_build(GetGpuScene(scene).Handle(), &p, &handle, nullptr) != RTX_OK) {
+        GpuScene& gs = GetGpuScene(scene);
+        if (gs.Group()) {
+            // several GPUs: every member traces its share of the photon ids, all of them end up holding the whole map
+            // (the reference's workers feed one map, :102-146); the group owns the maps, member 0's is the one queried here
+            if (rtx_group_photon_build(gs.Group(), &p, nullptr) != RTX_OK) {
+                std::cerr << "Photon map build failed: " << rtx_last_error() << "\n";
+                return;
+            }
+            handle = rtx_group_photons(gs.Group(), 0);
+            borrowed = true;
+        } else if (rtx_photon_build(gs.Handle(), &p, &handle, nullptr) != RTX_OK) {
             std::cerr << "Photon map build failed: " << rtx_last_error() << "\n";   // logged, render continues (:54-59)
             return;
         }
@@ -83,8 +92,14 @@ public:
     void SetSeed(uint64_t s) { seed = s; }
 
 private:
+    void Release() {
+        if (handle && !borrowed) rtx_photons_destroy(handle);
+        handle = nullptr;
+        borrowed = false;
+    }
     PhotonMap photonMap, causticsMap;
     rtx_photons* handle = nullptr;
+    bool borrowed = false;              // the handle belongs to a GPU group (SceneAdapter.h: g_rtDevices)
     int numPhotons = 10000000;          // PhotonMapBuilder.h:46-54
     float photonSearchRadius = 0.2f;
     float causticSearchRadius = 0.05f;

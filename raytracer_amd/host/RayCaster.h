@@ -3,10 +3,16 @@
 // frame is done, fills the RenderImage arrays (RayCaster.cpp:1183-1211) and may be cancelled from another thread.
 #pragma once
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <iostream>
+#include <memory>
+#include <string>
+#include <thread>
 #include "IntersectNodeAdapter.h"
 #include "PhotonMapBuilder.h"
+#include "SceneLoader.h"
 
 namespace rtamd {
 
@@ -31,6 +37,8 @@ struct SamplingConfig {
     int samplesPerPass = 0;           // samples per pixel in flight at once; 0 = sized from free HBM
     int progressiveSamplesPerPass = 1;   // kProgressiveSamplesPerPass, RayCaster.cpp:62
     bool legacyShading = false;       // SHADING_USE_LEGACY (ShadingConfig.h:7-13): TraceLegacy instead of TracePath
+    std::vector<int> devices;         // HIP devices to render on from this one process; sets g_rtDevices (SceneAdapter.h)
+                                      // before the scene is handed to the GPU. Empty: leave g_rtDevices as it is
 };
 
 class RayCaster {
@@ -42,6 +50,10 @@ public:
         const int W = camera->imgWidth, H = camera->imgHeight;
         std::cout << "CastRays: image size W=" << W << " H=" << H << "\n";
         stopFlag = false;
+        if (!sampling.devices.empty() && sampling.devices != g_rtDevices) {
+            ReleaseGpuScenes();   // the device copies are rebuilt on the new device list
+            g_rtDevices = sampling.devices;
+        }
         GpuScene& gs = GetGpuScene(scene);
         rtx_camera cam{};
         cam.pos[0] = camera->pos.x; cam.pos[1] = camera->pos.y; cam.pos[2] = camera->pos.z;
@@ -70,6 +82,21 @@ public:
         rtx_photons* ph = photonMapper ? photonMapper->Handle() : nullptr;
         rp.use_photons = ph ? 1 : 0;
         active = gs.Handle();
+        activeGroup = gs.Group();
+        if (gs.Group() && !progressivePreview) {
+            // the frame's buckets dealt to the GPUs of the group, films merged on the first one (rtx_group_render)
+            rp.use_photons = rtx_group_photons(gs.Group(), 0) && photonMapper ? 1 : 0;
+            int rc = rtx_group_render(gs.Group(), &cam, &rp, &image.GetLinearPixels()->r, &image.GetPixels()->r, image.GetZBuffer(),
+                                      image.GetSampleCount(), &image.GetAlbedo()->r, &image.GetNormal()->x, &lastStats);
+            active = nullptr;
+            activeGroup = nullptr;
+            if (rc != RTX_OK) {
+                std::cerr << "CastRays failed: " << rtx_last_error() << "\n";
+                return;
+            }
+            image.IncrementNumRenderPixel(W * H);
+            return;
+        }
         if (progressivePreview) {
             CastRaysProgressive(image, gs.Handle(), cam, rp, ph);
             active = nullptr;
@@ -146,7 +173,8 @@ public:
     }
     void Stop() {
         stopFlag = true;
-        if (rtx_scene* s = active.load()) rtx_cancel(s);
+        if (rtx_group* g = activeGroup.load()) rtx_group_cancel(g);
+        else if (rtx_scene* s = active.load()) rtx_cancel(s);
     }
     bool IsStopped() const { return stopFlag.load(); }
     void SetProgressivePreview(bool progressive) { progressivePreview = progressive; }
@@ -159,10 +187,11 @@ private:
     Camera* camera;
     std::atomic<bool> stopFlag{false};
     std::atomic<rtx_scene*> active{nullptr};
+    std::atomic<rtx_group*> activeGroup{nullptr};
     bool progressivePreview = false;
 };
 
-// RayCaster.h:82-83, RayCaster.cpp:1406-1422
+// RayCaster.h:82-83, RayCaster.cpp:1406-1422 (free-function forms; RayCastRenderer below is the reference's class)
 inline bool TraceRay(const Scene& scene, Ray const& ray, HitInfo& hInfo, int hitSide = HIT_FRONT_AND_BACK) {
     hInfo.Init();
     ExtendedHitInfo h;
@@ -183,5 +212,155 @@ inline bool TraceShadowRay(const Scene& scene, Ray const& ray, float t_max, int 
     }
     return true;
 }
+
+// Stand-in for the framework's Renderer base as far as RayCastRenderer uses it (renderer.h is not in the reference
+// repository): owns the Scene, the Camera and the RenderImage; LoadScene goes through the host's scene loader.
+class Renderer {
+public:
+    virtual ~Renderer() = default;
+    Scene& GetScene() { return scene; }
+    Scene const& GetScene() const { return scene; }
+    Camera& GetCamera() { return camera; }
+    RenderImage& GetRenderImage() { return renderImage; }
+    bool IsRendering() const { return isRendering; }
+    // framework Renderer::LoadScene (xmlload.cpp, absent): the host's loader for the cerealBar.xml dialect (SceneLoader.h)
+    virtual bool LoadScene(char const* sceneFilename) {
+        LoadedScene ls;
+        SceneLoader loader;
+        loader.allowMissingMeshes = true;
+        std::string err;
+        if (!loader.Load(sceneFilename, ls, err)) {
+            std::cerr << "LoadScene failed: " << err << "\n";
+            return false;
+        }
+        ReleaseGpuScenes();            // device copies of the scene that is being replaced
+        scene = std::move(ls.scene);
+        camera = ls.camera;
+        renderImage.Init(camera.imgWidth, camera.imgHeight);
+        return true;
+    }
+    virtual void BeginRender() = 0;
+    virtual void StopRender() = 0;
+    virtual bool TraceRay(Ray const& ray, HitInfo& hInfo, int hitSide = HIT_FRONT_AND_BACK) const = 0;
+    virtual bool TraceShadowRay(Ray const& ray, float t_max, int hitSide = HIT_FRONT_AND_BACK) const = 0;
+    virtual PhotonMap const* GetPhotonMap() const { return nullptr; }
+    virtual PhotonMap const* GetCausticsMap() const { return nullptr; }
+
+protected:
+    Scene scene;
+    Camera camera;
+    RenderImage renderImage;
+    std::atomic<bool> isRendering{false};
+};
+
+// RayCaster.h:66-117 / RayCaster.cpp:1321-1430: the renderer that runs RayCaster::CastRays on a background thread and
+// answers the framework's single-ray queries. Same members and semantics; the denoise hook is the host's (Denoiser.h).
+class RayCastRenderer : public Renderer {
+public:
+    RayCastRenderer() = default;
+    ~RayCastRenderer() override { StopRender(); }
+
+    bool LoadScene(char const* sceneFilename) override {
+        if (!Renderer::LoadScene(sceneFilename)) return false;
+        raycaster = std::make_unique<RayCaster>(&GetScene(), &GetCamera());
+        raycaster->SetProgressivePreview(progressivePreview);
+        return true;
+    }
+    // a scene built in memory instead of loaded from XML (the stand-in Renderer owns it: fill GetScene()/GetCamera() first)
+    void AttachScene() {
+        raycaster = std::make_unique<RayCaster>(&GetScene(), &GetCamera());
+        raycaster->SetProgressivePreview(progressivePreview);
+    }
+    RayCaster* GetRayCaster() { return raycaster.get(); }
+
+    // RayCaster.cpp:1321-1398
+    void BeginRender() override {
+        if (!raycaster) return;
+        if (renderThread.joinable()) renderThread.join();
+        isRendering = true;
+        renderThread = std::thread([this]() {
+            try {
+                const auto t0 = std::chrono::steady_clock::now();
+                raycaster->CastRays(this->GetRenderImage(), photonMapper);
+                const double total_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                const int hours = (int)total_seconds / 3600, minutes = ((int)total_seconds % 3600) / 60, seconds = (int)total_seconds % 60;
+                char buf[32];
+                std::snprintf(buf, sizeof(buf), "%02d:%02d:%02d", hours, minutes, seconds);
+                std::cout << "Render time: " << buf << "\n";
+                if (!isPreviewMode) {
+                    if (autoSaveOutputs) {
+                        this->GetRenderImage().ComputeZBufferImage();
+                        this->GetRenderImage().ComputeSampleCountImage();
+                        this->GetRenderImage().SaveImage(outputColorPath.c_str());
+                        this->GetRenderImage().SaveZImage(outputZPath.c_str());
+                        this->GetRenderImage().SaveSampleCountImage(outputSamplesPath.c_str());
+                    }
+                    isRendering = false;
+                }
+                // preview mode keeps isRendering set so that the viewport stays open (RayCaster.cpp:1385)
+            } catch (const std::exception& e) {
+                std::cerr << "Render thread exception: " << e.what() << "\n";
+                isRendering = false;
+            } catch (...) {
+                std::cerr << "Render thread unknown exception.\n";
+                isRendering = false;
+            }
+        });
+    }
+    // RayCaster.cpp:1400-1404
+    void StopRender() override {
+        if (raycaster) raycaster->Stop();
+        if (renderThread.joinable()) renderThread.join();
+        isRendering = false;
+    }
+    // blocks until the frame started by BeginRender is done (Main.cpp:354-358 polls IsRendering every 50 ms instead)
+    void WaitRender() {
+        if (renderThread.joinable()) renderThread.join();
+    }
+
+    // RayCaster.cpp:1406-1410
+    bool TraceRay(Ray const& ray, HitInfo& hInfo, int hitSide = HIT_FRONT_AND_BACK) const override {
+        hInfo.Init();
+        return IntersectNode(&GetScene().rootNode, ray, hInfo, hitSide);
+    }
+    // RayCaster.cpp:1412-1422 (declared bool, returns 0.0f / 1.0f: false = occluded before t_max)
+    bool TraceShadowRay(Ray const& ray, float t_max, int hitSide = HIT_FRONT_AND_BACK) const override {
+        HitInfo h;
+        h.Init();
+        if (IntersectNode(&GetScene().rootNode, ray, h, hitSide)) {
+            const float d = (h.p - ray.p).Length();
+            if (d < t_max) return 0.0f;
+        }
+        return 1.0f;
+    }
+    PhotonMap const* GetPhotonMap() const override { return photonMapper ? photonMapper->GetPhotonMap() : nullptr; }       // :1424-1426
+    PhotonMap const* GetCausticsMap() const override { return photonMapper ? photonMapper->GetCausticsMap() : nullptr; }   // :1428-1430
+
+    void SetPreviewMode(bool preview) { isPreviewMode = preview; }
+    void SetProgressivePreview(bool progressive) {
+        progressivePreview = progressive;
+        if (raycaster) raycaster->SetProgressivePreview(progressive);
+    }
+    void SetOutputPaths(const std::string& color, const std::string& z, const std::string& samples, const std::string& denoised) {
+        outputColorPath = color;
+        outputZPath = z;
+        outputSamplesPath = samples;
+        outputDenoisedPath = denoised;
+    }
+    void SetAutoSaveOutputs(bool enable) { autoSaveOutputs = enable; }
+    void SetPhotonMapper(PhotonMapBuilder* mapper) { photonMapper = mapper; }
+
+private:
+    std::unique_ptr<RayCaster> raycaster;
+    std::thread renderThread;
+    bool isPreviewMode = false;
+    bool progressivePreview = false;
+    PhotonMapBuilder* photonMapper = nullptr;
+    std::string outputColorPath = "render.png";
+    std::string outputZPath = "zbuffer.png";
+    std::string outputSamplesPath = "samples.png";
+    std::string outputDenoisedPath = "render_denoised.png";
+    bool autoSaveOutputs = true;
+};
 
 }  // namespace rtamd

@@ -36,14 +36,26 @@ inline void CollectSceneNodeItems(const Scene& scene, std::vector<SceneNodeItem>
     walk(root ? root : &scene.rootNode, Matrix34(), walk);
 }
 
-// Device-resident copy of a Scene (or of a sub-tree rooted at `root`). Owns the rtx_scene handle.
+// The GPUs this process renders on, set by the host before the first frame like the reference's run-time globals
+// (g_rtUseBBox, g_rtUseMeshBVH: Main.cpp:24-26). Empty or one entry: the current HIP device only. Several entries: every
+// scene handed to the GPU is replicated on those devices (rtx_group), RayCaster::CastRays deals the 16x16 buckets
+// to them as the reference deals them to its worker threads (RayCaster.cpp:1281-1312) and PhotonMapBuilder splits the
+// photon ids; single-ray queries (IntersectNode, TraceRay ...) run on the first device of the list, which must be the
+// calling thread's current device.
+inline std::vector<int> g_rtDevices;
+
+// Device-resident copy of a Scene (or of a sub-tree rooted at `root`). Owns the rtx_scene / rtx_group handle.
 class GpuScene {
 public:
     GpuScene(const Scene& scene, const Node* root = nullptr) { Build(scene, root ? root : &scene.rootNode); }
-    ~GpuScene() { rtx_scene_destroy(handle); }
+    ~GpuScene() {
+        if (group) rtx_group_destroy(group);   // owns the member scenes, `handle` among them
+        else rtx_scene_destroy(handle);
+    }
     GpuScene(const GpuScene&) = delete;
     GpuScene& operator=(const GpuScene&) = delete;
     rtx_scene* Handle() const { return handle; }
+    rtx_group* Group() const { return group; }   // non-null when the scene lives on several GPUs (g_rtDevices)
     // (Node, Object) pair of flattened object index i, in CollectSceneNodeObjects order (TriObj, Sphere, Plane)
     const Node* NodeOf(int obj) const { return obj >= 0 && obj < (int)nodes.size() ? nodes[obj] : nullptr; }
     int IndexOf(const Node* n) const {
@@ -55,6 +67,7 @@ public:
 
 private:
     rtx_scene* handle = nullptr;
+    rtx_group* group = nullptr;
     std::vector<const Node*> nodes;
     std::vector<Light*> lights;
 
@@ -156,7 +169,12 @@ private:
         sd.materials = mtls.data();     sd.n_materials = (int)mtls.size();
         sd.texmaps = tex.descs.data();  sd.n_texmaps = (int)tex.descs.size();
         sd.lights = ls.data();          sd.n_lights = (int)ls.size();
-        if (rtx_scene_create(&sd, &handle) != RTX_OK) throw std::runtime_error(std::string("rtx_scene_create: ") + rtx_last_error());
+        if (g_rtDevices.size() > 1) {
+            if (rtx_group_create(&sd, g_rtDevices.data(), (int)g_rtDevices.size(), &group) != RTX_OK)
+                throw std::runtime_error(std::string("rtx_group_create: ") + rtx_last_error());
+            handle = rtx_group_scene(group, 0);
+        } else if (rtx_scene_create(&sd, &handle) != RTX_OK)
+            throw std::runtime_error(std::string("rtx_scene_create: ") + rtx_last_error());
     }
 };
 

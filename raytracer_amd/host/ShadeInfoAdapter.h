@@ -10,8 +10,28 @@
 
 namespace rtamd {
 
-class ShadeInfoAdapter {
+// Stand-ins for the framework types in the reference's constructor signature (rng.h, scene.h: ShadeInfo are not in the
+// reference repository). The random numbers of the GPU path come from the counter RNG keyed by (seed, pixel, sample,
+// recursion node) in both the oracle and the kernels (deviation 1), so the RNG& is accepted and not drawn from.
+class RNG {
 public:
+    RNG() = default;
+    explicit RNG(uint64_t s) : state(s) {}
+    void SetSequence(uint64_t s) { state = s; }
+    uint64_t state = 0;
+};
+class ShadeInfo {
+public:
+    virtual ~ShadeInfo() = default;
+    virtual float TraceShadowRay(Ray const& r, float t_max = BIGFLOAT) const = 0;
+    virtual Color TraceSecondaryRay(Ray const& r, float& dist, bool recursive = true, bool isReflection = true) const = 0;
+};
+
+class ShadeInfoAdapter : public ShadeInfo {
+public:
+    // ShadeInfoAdapter.h:21 (the reference's signature)
+    ShadeInfoAdapter(const std::vector<Light*>& lightList, const Scene* scenePtr, RNG& r) : lights(lightList), scene(scenePtr), rng(&r) {}
+    // without a caller-owned RNG (the counter RNG needs none)
     ShadeInfoAdapter(const std::vector<Light*>& lightList, const Scene* scenePtr) : lights(lightList), scene(scenePtr) {}
 
     void SetHit(Ray const& r, HitInfo const& h) {
@@ -23,7 +43,7 @@ public:
     const Node* GetNode() const { return hit.node; }
 
     // ShadeInfoAdapter.h:49-88
-    float TraceShadowRay(Ray const& r, float t_max = BIGFLOAT) const {
+    float TraceShadowRay(Ray const& r, float t_max = BIGFLOAT) const override {
         if (!scene) return 1.0f;
         const float Llen = r.dir.Length();
         if (Llen < 1e-12f) return 1.0f;
@@ -70,7 +90,7 @@ public:
     // ShadeInfoAdapter.h:94-231. inRay.p is not read by the reference either (the ray starts at the biased P(), :111).
     // Both values of isReflection lead to the same result (:115-183); it selects the RNG node of the hit:
     // reflection = child 2, otherwise child 1.
-    Color TraceSecondaryRay(Ray const& inRay, float& dist, bool recursive = true, bool isReflection = true) const {
+    Color TraceSecondaryRay(Ray const& inRay, float& dist, bool recursive = true, bool isReflection = true) const override {
         dist = BIGFLOAT;
         if (!scene) return Color(0, 0, 0);
         if (!CanBounce()) return Color(0, 0, 0);
@@ -113,6 +133,7 @@ private:
     }
     std::vector<Light*> lights;
     const Scene* scene;
+    RNG* rng = nullptr;
     HitInfo hit;
     Vec3f view;
     const PhotonMapBuilder* mapper = nullptr;

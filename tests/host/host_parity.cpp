@@ -479,6 +479,80 @@ int main() {
         if (fp) std::fclose(fp);
     }
 
+    // several GPUs from this one process (SamplingConfig::devices -> rtx_group): two members sharing the test GPU must
+    // reproduce the single-device frame - same sample counts and z, colour up to float summation order - with and
+    // without the photon map (every member traces half of the photon ids, all hold the whole map afterwards)
+    {
+        ReleaseGpuScenes();
+        RayCaster rg(&scene, &cam);
+        rg.sampling.minSamples = rg.sampling.maxSamples = 8;
+        rg.sampling.devices = {0, 0};
+        RenderImage imgG;
+        imgG.Init(cam.imgWidth, cam.imgHeight);
+        rg.CastRays(imgG);
+        CHECK(GetGpuScene(&scene).Group() != nullptr && rtx_group_size(GetGpuScene(&scene).Group()) == 2, "the scene lives in a 2-member group");
+        int badG = 0;
+        double dG = 0;
+        for (size_t i = 0; i < np; ++i) {
+            const Color &a = imgG.GetLinearPixels()[i], &b = img.GetLinearPixels()[i];
+            dG = std::max(dG, (double)std::max(std::fabs(a.r - b.r), std::max(std::fabs(a.g - b.g), std::fabs(a.b - b.b))) / (1.0 + b.r + b.g + b.b));
+            if (imgG.GetSampleCount()[i] != img.GetSampleCount()[i] || imgG.GetZBuffer()[i] != img.GetZBuffer()[i]) ++badG;
+        }
+        CHECK(badG == 0 && dG < 2e-4, "group CastRays vs single device: %d counts / z differ, max relative colour difference %.2e", badG, dG);
+        PhotonMapBuilder pmg;
+        pmg.SetNumPhotons(200000);
+        pmg.BuildPhotonMap(&scene);
+        CHECK(pmg.GetPhotonMap()->NumPhotons() == pmb.GetPhotonMap()->NumPhotons() && pmg.GetCausticsMap()->NumPhotons() == pmb.GetCausticsMap()->NumPhotons(),
+              "group photon map holds the single-device counts (%d / %d vs %d / %d)", pmg.GetPhotonMap()->NumPhotons(),
+              pmg.GetCausticsMap()->NumPhotons(), pmb.GetPhotonMap()->NumPhotons(), pmb.GetCausticsMap()->NumPhotons());
+        RenderImage imgGP;
+        imgGP.Init(cam.imgWidth, cam.imgHeight);
+        rg.CastRays(imgGP, &pmg);
+        double dP = 0;
+        for (size_t i = 0; i < np; ++i) {
+            const Color &a = imgGP.GetLinearPixels()[i], &b = img2.GetLinearPixels()[i];
+            dP = std::max(dP, (double)std::max(std::fabs(a.r - b.r), std::max(std::fabs(a.g - b.g), std::fabs(a.b - b.b))) / (1.0 + b.r + b.g + b.b));
+        }
+        CHECK(dP < 1e-3, "group CastRays with photons vs single device: max relative difference %.2e", dP);
+        g_rtDevices.clear();
+        ReleaseGpuScenes();
+    }
+
+    // RayCastRenderer (RayCaster.h:66-117): LoadScene -> BeginRender on its own thread -> outputs; single-ray queries
+    {
+        RayCastRenderer rr;
+        CHECK(rr.LoadScene("/tmp/rtamd_scene.xml"), "RayCastRenderer::LoadScene");
+        rr.GetRayCaster()->sampling.minSamples = rr.GetRayCaster()->sampling.maxSamples = 4;
+        rr.GetRayCaster()->sampling.maxBounces = 4;
+        rr.SetOutputPaths("/tmp/rtamd_rr_render.png", "/tmp/rtamd_rr_z.png", "/tmp/rtamd_rr_samples.png", "/tmp/rtamd_rr_denoised.png");
+        PhotonMapBuilder none;
+        CHECK(rr.GetPhotonMap() == nullptr && rr.GetCausticsMap() == nullptr, "no photon mapper set");
+        rr.SetPhotonMapper(&none);
+        CHECK(rr.GetPhotonMap() == none.GetPhotonMap() && rr.GetCausticsMap() == none.GetCausticsMap(), "photon map getters forward to the mapper");
+        rr.SetPhotonMapper(nullptr);
+        rr.BeginRender();
+        rr.WaitRender();
+        CHECK(!rr.IsRendering(), "offline render clears isRendering when done");
+        double meanr = 0;
+        for (int i = 0; i < 80 * 48; ++i) meanr += rr.GetRenderImage().GetLinearPixels()[i].r;
+        CHECK(meanr / (80 * 48) > 0.02, "RayCastRenderer frame (mean %.4f)", meanr / (80 * 48));
+        FILE* fr = std::fopen("/tmp/rtamd_rr_render.png", "rb");
+        CHECK(fr != nullptr, "RayCastRenderer saved its outputs");
+        if (fr) std::fclose(fr);
+        HitInfo hr;
+        Ray toBall(rr.GetCamera().pos, (Vec3f(1.4f, 0.6f, 0.0f) - rr.GetCamera().pos).GetNormalized());
+        const float expectT = (Vec3f(1.4f, 0.6f, 0.0f) - rr.GetCamera().pos).Length() - 0.6f;
+        CHECK(rr.TraceRay(toBall, hr) && std::fabs(hr.z - expectT) < 1e-4f, "RayCastRenderer::TraceRay");
+        CHECK(!rr.TraceShadowRay(toBall, expectT * 2.0f) && rr.TraceShadowRay(toBall, expectT * 0.5f), "RayCastRenderer::TraceShadowRay");
+        RNG rng(7);
+        ShadeInfoAdapter sir(rr.GetScene().lights, &rr.GetScene(), rng);   // the reference's constructor (ShadeInfoAdapter.h:21)
+        const ShadeInfo& base = sir;
+        HitInfo fh; fh.Init(); fh.p = Vec3f(0.5f, 0.0f, 1.0f); fh.N = Vec3f(0, 1, 0); fh.node = nullptr;
+        sir.SetHit(Ray(Vec3f(0.5f, 3, 1), Vec3f(0, -1, 0)), fh);
+        CHECK(base.TraceShadowRay(Ray(fh.p, Vec3f(0, 1, 0)), BIGFLOAT) == 1.0f, "ShadeInfo::TraceShadowRay through the base class");
+        ReleaseGpuScenes();
+    }
+
     ReleaseGpuScenes();
     orc_scene_destroy(osc);
     std::printf(failures ? "host_parity: %d FAILURES\n" : "host_parity: all checks passed\n", failures);

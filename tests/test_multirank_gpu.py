@@ -62,3 +62,84 @@ def test_all_gathered_photon_map_equals_single_rank_map(runs):
     for r in (r0, r1):
         d = np.abs(r["caustic_samples"] - one["caustic_samples"]).max(-1)
         assert (d <= 1e-4 * (1 + np.abs(one["caustic_samples"]).max(-1))).mean() >= 0.999
+
+
+# ---- several members in ONE process (rtx_group: the C++ host's multi-GPU path) ----------------------------------
+# The test box has one GPU: members share it (device ids repeat), which exercises everything but the peer copies
+# themselves (a member on the root's device is merged in place).
+
+@pytest.fixture(scope="module")
+def group_env(rtx):
+    from raytracer_amd import synth
+    sd = synth.build_scene(0.003)
+    return sd, rtx.Scene(sd), synth.cerealbar_camera(96, 54)
+
+
+@pytest.mark.parametrize("members", [1, 2, 3])
+def test_group_render_equals_single_device(group_env, rtx, members):
+    from raytracer_amd.scene import render_params
+    sd, gs, cam = group_env
+    grp = rtx.Group(sd, [0] * members)
+    rp = render_params(spp_min=4, max_bounces=8)
+    ref = gs.render(cam, rp)
+    got = grp.render(cam, rp)
+    assert np.array_equal(got["samples"], ref["samples"]) and (got["samples"] == 4).all()
+    assert np.array_equal(got["z"], ref["z"])
+    assert np.allclose(got["linear"], ref["linear"], rtol=2e-4, atol=2e-5)          # float summation order only
+    for k in ("rays_primary", "rays_bounce", "rays_shadow", "paths"):
+        assert got["stats"][k] == ref["stats"][k]
+    # guides: first-hit albedo / normal of every pixel, whichever member owns it
+    import torch
+    from raytracer_amd import _ffi
+    n = cam.width * cam.height
+    t = [torch.empty((n, 4), device="cuda:0"), torch.empty(n, dtype=torch.int32, device="cuda:0"), torch.empty(n, device="cuda:0"),
+         torch.empty((n, 4), device="cuda:0"), torch.empty((n, 4), device="cuda:0")]
+    f = _ffi.Film(*[x.data_ptr() for x in t])
+    rtx.film_clear(f, cam.width, cam.height)
+    gs.render_accumulate(cam, rp, f)
+    one = rtx.film_resolve(f, cam, want_aov=True)
+    assert np.array_equal(got["albedo"], one["albedo"]) and np.array_equal(got["normal"], one["normal"])
+    # adaptive sampling per member on its own buckets: a pixel's decision uses only its own samples, so the maps agree
+    rpa = render_params(spp_min=8, spp_max=32, max_bounces=8, ci_halfwidth=0.02)
+    a, b = grp.render(cam, rpa), gs.render(cam, rpa)
+    assert np.array_equal(a["samples"], b["samples"]) and (a["samples"] > 8).any()
+    assert np.allclose(a["linear"], b["linear"], rtol=2e-4, atol=2e-5)
+    grp.close()
+
+
+def test_group_photon_map_equals_single_device(group_env, rtx):
+    from raytracer_amd.scene import render_params
+    from raytracer_amd import synth
+    sd, gs, cam = group_env
+    N = 200000
+    single = rtx.Photons(gs, num_photons=N)
+    grp = rtx.Group(sd, [0, 0])
+    with pytest.raises(rtx.RtxError, match="no photon map"):
+        grp.member_photons(0)
+    st = grp.photon_build(num_photons=N)
+    assert st["rays_photon"] == single.stats["rays_photon"]
+    pos = single.download(1)["pos"]
+    probe = (pos[:: max(1, len(pos) // 200)][:200] + np.float32(0.002)).astype(np.float32)
+    nrm = np.tile(np.array([[0, 1, 0]], np.float32), (len(probe), 1))
+    for member in (0, 1):
+        ph = grp.member_photons(member)
+        assert ph.info() == single.info()
+        for which in (0, 1):
+            ref = single.estimate(which, probe, nrm)
+            assert np.abs(ref).max() > 0
+            assert np.allclose(ph.estimate(which, probe, nrm), ref, rtol=1e-3, atol=1e-6 * np.abs(ref).max())
+    small = synth.cerealbar_camera(48, 27)
+    rp = render_params(spp_min=4, max_bounces=4, use_photons=1)
+    a, b = grp.render(small, rp), gs.render(small, rp, single)
+    assert np.allclose(a["linear"], b["linear"], rtol=1e-3, atol=1e-5)
+    dark = gs.render(small, render_params(spp_min=4, max_bounces=4))
+    assert np.abs(b["linear"] - dark["linear"]).max() > 1e-4                        # the caustic map does contribute
+    grp.close()
+
+
+def test_group_rejects_bad_arguments(group_env, rtx):
+    sd, gs, cam = group_env
+    with pytest.raises(rtx.RtxError, match="out of range"):
+        rtx.Group(sd, [0, 99])
+    with pytest.raises(rtx.RtxError, match="RTX_GROUP_MAX"):
+        rtx.Group(sd, [0] * 17)
