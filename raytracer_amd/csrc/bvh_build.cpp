@@ -176,7 +176,6 @@ struct Emitter {
     const std::vector<SrcTri>& src;
     const rtx_scene_desc* desc;
     const std::vector<int>& faceBase;
-    const std::vector<float>& itm;  // 12 per mesh: inverse of xform (normals use its transpose)
     HostScene& out;
     int maxDepth = 0;
     std::string err;
@@ -184,10 +183,22 @@ struct Emitter {
     void emit_tri(int p) {
         const SrcTri& t = src[p];
         TriRec r;
-        r.v0x = t.v[0][0]; r.v0y = t.v[0][1]; r.v0z = t.v[0][2];
-        // e1 = v1 - v0, e2 = v2 - v0 in fp32: the operands the reference forms per test (objects.cpp:146-147)
-        r.e1x = t.v[1][0] - t.v[0][0]; r.e1y = t.v[1][1] - t.v[0][1]; r.e1z = t.v[1][2] - t.v[0][2];
-        r.e2x = t.v[2][0] - t.v[0][0]; r.e2y = t.v[2][1] - t.v[0][1]; r.e2z = t.v[2][2] - t.v[0][2];
+        if (t.kind == (int)RTX_KIND_XFTRI) {
+            // mesh under a non-identity node transform: the object's own fp32 vertices (the kernels carry the ray to node
+            // coordinates, IntersectNodeAdapter.h:62); t.v holds the world-space corners the BVH boxes were built from
+            const rtx_mesh_desc& m = desc->meshes[t.obj];
+            const float* v0 = m.v + 3 * (size_t)m.f[3 * (size_t)t.face];
+            const float* v1 = m.v + 3 * (size_t)m.f[3 * (size_t)t.face + 1];
+            const float* v2 = m.v + 3 * (size_t)m.f[3 * (size_t)t.face + 2];
+            r.v0x = v0[0]; r.v0y = v0[1]; r.v0z = v0[2];
+            r.e1x = v1[0] - v0[0]; r.e1y = v1[1] - v0[1]; r.e1z = v1[2] - v0[2];
+            r.e2x = v2[0] - v0[0]; r.e2y = v2[1] - v0[1]; r.e2z = v2[2] - v0[2];
+        } else {
+            r.v0x = t.v[0][0]; r.v0y = t.v[0][1]; r.v0z = t.v[0][2];
+            // e1 = v1 - v0, e2 = v2 - v0 in fp32: the operands the reference forms per test (objects.cpp:146-147)
+            r.e1x = t.v[1][0] - t.v[0][0]; r.e1y = t.v[1][1] - t.v[0][1]; r.e1z = t.v[1][2] - t.v[0][2];
+            r.e2x = t.v[2][0] - t.v[0][0]; r.e2y = t.v[2][1] - t.v[0][1]; r.e2z = t.v[2][2] - t.v[0][2];
+        }
         // opaque for shadow rays: no material, or max(Refraction().GetValue()) <= 0 (RayCaster.cpp:215-229)
         const int objMtl = desc->meshes[t.obj].material;
         bool opaque = true;
@@ -199,7 +210,7 @@ struct Emitter {
         r.obj = (uint32_t)t.obj | (opaque ? TRI_OPAQUE : 0u);
         r.prim = (uint32_t)(faceBase[t.obj] + t.face);
         out.tris.push_back(r);
-        if (t.kind != RTX_OBJ_MESH) {
+        if (t.kind != RTX_OBJ_MESH && t.kind != (int)RTX_KIND_XFTRI) {
             TriAttr a;
             std::memset(&a, 0, sizeof(a));
             a.obj_mtl = (uint32_t)t.obj;
@@ -208,29 +219,21 @@ struct Emitter {
         }
 
         const rtx_mesh_desc& m = desc->meshes[t.obj];
-        const bool mir = (out.objs[t.obj].flags & OBJ_MIRRORED) != 0u;   // v1 and v2 are exchanged in t.v
         TriAttr a;
         std::memset(&a, 0, sizeof(a));
         if (m.vn && m.nvn > 0) {
+            // object-space normals: for a transformed mesh the interpolated normal goes to the world with the hit
+            // (Node::FromNodeCoords, surface.h); the transform is the identity for every cerealBar object
             const int* fn = (m.fn ? m.fn : m.f) + 3 * (size_t)t.face;
-            float* dst[3] = {a.n0, mir ? a.n2 : a.n1, mir ? a.n1 : a.n2};
+            float* dst[3] = {a.n0, a.n1, a.n2};
             for (int k = 0; k < 3; ++k) {
                 const float* n = m.vn + 3 * (size_t)fn[k];
-                // normals go to world space by the inverse-transpose (Node::FromNodeCoords); the transform is
-                // the identity for every cerealBar object
-                const float* M = &itm[12 * (size_t)t.obj];
-                if (is_identity(m.xform)) {
-                    dst[k][0] = n[0]; dst[k][1] = n[1]; dst[k][2] = n[2];
-                } else {
-                    dst[k][0] = M[0] * n[0] + M[4] * n[1] + M[8] * n[2];
-                    dst[k][1] = M[1] * n[0] + M[5] * n[1] + M[9] * n[2];
-                    dst[k][2] = M[2] * n[0] + M[6] * n[1] + M[10] * n[2];
-                }
+                dst[k][0] = n[0]; dst[k][1] = n[1]; dst[k][2] = n[2];
             }
         }
         if (m.vt && m.nvt > 0) {
             const int* ft = (m.ft ? m.ft : m.f) + 3 * (size_t)t.face;
-            float* dst[3] = {a.uv0, mir ? a.uv2 : a.uv1, mir ? a.uv1 : a.uv2};
+            float* dst[3] = {a.uv0, a.uv1, a.uv2};
             for (int k = 0; k < 3; ++k) {
                 const float* uv = m.vt + 3 * (size_t)ft[k];
                 dst[k][0] = uv[0]; dst[k][1] = uv[1];
@@ -398,12 +401,8 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
         ObjRec& o = out.objs[m];
         o.material = md.material;
         o.flags = ((md.vn && md.nvn > 0) ? OBJ_HAS_NORMALS : 0u) | ((md.vt && md.nvt > 0) ? OBJ_HAS_TEXCOORDS : 0u);
-        // The reference intersects in object space and takes GN = normalize(itm^T (e1 x e2)) to the world
-        // (IntersectNodeAdapter.h:62,93). World-space edges give (M e1) x (M e2) = det(M) M^-T (e1 x e2): under a
-        // mirroring transform the baked triangle would face the other way. Exchanging v1 and v2 (and their attributes)
-        // restores the reference's geometric normal and front/back decision; the barycentrics (u, v) swap with them.
-        const bool mirrored = md.kind == RTX_OBJ_MESH && !ident && det33(md.xform) < 0.0;
-        if (mirrored) o.flags |= OBJ_MIRRORED;
+        // The reference intersects in object space (IntersectNodeAdapter.h:62,93): a mesh under a non-identity transform
+        // keeps its object-space vertices (RTX_KIND_XFTRI records); only its BVH boxes are in world space
         if (md.kind == RTX_OBJ_MESH && !ident) o.flags |= OBJ_TRANSFORMED;
         o.face_base = faceBase[m];
         if (md.kind != RTX_OBJ_MESH) {
@@ -455,14 +454,14 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
             SrcTri& t = src[(size_t)faceBase[m] + f];
             t.obj = m;
             t.face = f;
-            t.kind = RTX_OBJ_MESH;
+            t.kind = ident ? RTX_OBJ_MESH : (int)RTX_KIND_XFTRI;
             for (int k = 0; k < 3; ++k) {
                 int vi = md.f[3 * (size_t)f + k];
                 if (vi < 0 || vi >= md.nv) {
                     err = "mesh " + std::to_string(m) + ": vertex index out of range";
                     return false;
                 }
-                float* dstv = t.v[(mirrored && k) ? 3 - k : k];
+                float* dstv = t.v[k];
                 if (ident) std::memcpy(dstv, md.v + 3 * (size_t)vi, 12);
                 else {
                     xf_point(md.xform, md.v + 3 * (size_t)vi, dstv);
@@ -500,9 +499,32 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
     B.pbox.resize(total);
     B.cen.resize(3 * total);
     B.idx.resize(total);
+    // conditioning of every transform: how far a rounding error of the object-space test can sit from the world-space box
+    std::vector<float> kappa(std::max(1, desc->n_meshes), 1.0f);
+    for (int m = 0; m < desc->n_meshes; ++m) {
+        const float* F = out.objXf[m].fwd;
+        const float* I = out.objXf[m].inv;
+        float nf = 0.0f, ni = 0.0f;
+        for (int r = 0; r < 3; ++r) {
+            nf = std::max(nf, std::fabs(F[4 * r]) + std::fabs(F[4 * r + 1]) + std::fabs(F[4 * r + 2]));
+            ni = std::max(ni, std::fabs(I[4 * r]) + std::fabs(I[4 * r + 1]) + std::fabs(I[4 * r + 2]));
+        }
+        kappa[m] = std::max(1.0f, nf * ni);
+    }
     for (size_t i = 0; i < total; ++i) {
         AABB b;
         for (int k = 0; k < 3; ++k) b.add(src[i].v[k]);
+        if (src[i].kind == (int)RTX_KIND_XFTRI) {
+            // the triangle is tested in object space, its box lives in world space: the two agree up to the rounding of
+            // the transform, so the box gets a margin of a few ulp of its coordinates, scaled by the transform's conditioning
+            float mag = 0.0f;
+            for (int a = 0; a < 3; ++a) mag = std::max(mag, std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
+            const float pad = 4e-6f * kappa[src[i].obj] * mag + 1e-30f;
+            for (int a = 0; a < 3; ++a) {
+                b.lo[a] -= pad;
+                b.hi[a] += pad;
+            }
+        }
         B.pbox[i] = b;
         for (int a = 0; a < 3; ++a) B.cen[3 * i + a] = 0.5f * (b.lo[a] + b.hi[a]);
         B.idx[i] = (int)i;
@@ -516,7 +538,7 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
     out.tris.reserve(total);
     out.attrs.reserve(total);
     out.nodes.reserve(total / 2 + 16);
-    Emitter E{B, src, desc, faceBase, itm, out};
+    Emitter E{B, src, desc, faceBase, out};
     out.root = E.emit(root, 0);
     out.depth = E.maxDepth;
     if (!E.err.empty()) {
@@ -546,9 +568,20 @@ struct Validator {
                 float v0[3] = {t.v0x, t.v0y, t.v0z};
                 float v1[3] = {t.v0x + t.e1x, t.v0y + t.e1y, t.v0z + t.e1z};
                 float v2[3] = {t.v0x + t.e2x, t.v0y + t.e2y, t.v0z + t.e2z};
-                b.add(v0);
-                b.add(v1);
-                b.add(v2);
+                if (t.kind == RTX_KIND_XFTRI) {   // object-space record: its box is the world-space one
+                    const float* F = hs.objXf[t.obj & TRI_OBJ_MASK].fwd;
+                    float w0[3], w1[3], w2[3];
+                    xf_point(F, v0, w0);
+                    xf_point(F, v1, w1);
+                    xf_point(F, v2, w2);
+                    b.add(w0);
+                    b.add(w1);
+                    b.add(w2);
+                } else {
+                    b.add(v0);
+                    b.add(v1);
+                    b.add(v2);
+                }
             }
             return b;
         }

@@ -45,8 +45,9 @@ struct LgState {
     LgCall stack[LG_STACK];
 };
 
-struct LgScene {
-    const DevScene& sc;
+template <class SC>
+struct LgSceneT {
+    const SC& sc;
     const DevPhotonMap& pmGlobal;
     const DevPhotonMap& pmCaustic;
     TravStack st;
@@ -83,7 +84,8 @@ __device__ __forceinline__ float lg_light_intersect(const DevLight& L, f3 o, f3 
 
 // ShadeInfoAdapter::TraceShadowRay (:49-88): one closest hit from the biased origin; the receiver's own node is
 // ignored close to the origin, a finite segment is blocked only before the light.
-__device__ __forceinline__ float lg_trace_shadow(const LgScene& g, const SampCtx& sx, int obj, f3 dir, float tMax, LgState& S) {
+template <class G>
+__device__ __forceinline__ float lg_trace_shadow(const G& g, const SampCtx& sx, int obj, f3 dir, float tMax, LgState& S) {
     const float Llen = len3(dir);
     if (Llen < 1e-12f) return 1.0f;
     const bool finiteSegment = tMax < RTX_BIG * 0.5f;
@@ -120,7 +122,8 @@ __device__ __forceinline__ float lg_trace_shadow(const LgScene& g, const SampCtx
 
 // PointLight::Illuminate (Shading_Legacy.cpp:115-210). TraceShadowRay returns exactly 0 or 1, so the first cone sample
 // is always "unanimous" (:189) and the 2nd..4th samples of the adaptive loop are never taken: one shadow ray per light.
-__device__ __forceinline__ f3 lg_illuminate(const LgScene& g, const SampCtx& sx, int obj, const DevLight& light, int l, f3& dir, LgState& S) {
+template <class G>
+__device__ __forceinline__ f3 lg_illuminate(const G& g, const SampCtx& sx, int obj, const DevLight& light, int l, f3& dir, LgState& S) {
     const f3 toC = ld3(light.pos) - sx.P;
     const float distC = len3(toC);
     if (distC < 1e-20f) {
@@ -366,10 +369,10 @@ __device__ __forceinline__ bool lg_generate_sample(const DevScene& sc, const Dev
 // One Shade() (Shading_Legacy.cpp:366-514 Blinn, :517-659 Phong, :662-694 microfacet) whose result enters the sample
 // with weight w: adds w x (its own terms) to S.L and queues its TraceSecondaryRay calls.
 // DEFER: the shadow queries of the lights are queued (lg_push_shadow) instead of traced here.
-template <bool DEFER>
-__device__ __forceinline__ void lg_shade(const LgScene& g, const DevMaterial& m, const SampCtx& sx, int obj, f3 w, int bounce,
+template <bool DEFER, class G>
+__device__ __forceinline__ void lg_shade(const G& g, const DevMaterial& m, const SampCtx& sx, int obj, f3 w, int bounce,
                                          int diffuseDepth, LgState& S) {
-    const DevScene& sc = g.sc;
+    const auto& sc = g.sc;
     const bool canBounce = bounce < LG_MAX_BOUNCES;
     const uint32_t node = sx.stream;
     if (m.type == RTX_MTL_MICROFACET) {
@@ -509,8 +512,9 @@ __device__ __forceinline__ void lg_shade(const LgScene& g, const DevMaterial& m,
 
 // TraceSecondaryRay from the biased ray on (ShadeInfoAdapter.h:114-230) for every queued call; firstDist receives the
 // `dist` result of the first call traced (the one a caller of rtx_trace_secondary asked for)
-__device__ __forceinline__ void lg_run(const LgScene& g, unsigned long long key, LgState& S, float* firstDist = nullptr) {
-    const DevScene& sc = g.sc;
+template <class G>
+__device__ __forceinline__ void lg_run(const G& g, unsigned long long key, LgState& S, float* firstDist = nullptr) {
+    const auto& sc = g.sc;
     bool first = true;
     while (S.sp > 0) {
         const LgCall c = S.stack[--S.sp];
@@ -576,8 +580,9 @@ __device__ __forceinline__ void lg_run(const LgScene& g, unsigned long long key,
 #ifndef LEGACY_WAVES_PER_EU
 #define LEGACY_WAVES_PER_EU 3
 #endif
+template <bool XF>
 __attribute__((amdgpu_waves_per_eu(LEGACY_WAVES_PER_EU)))
-__global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene sc, DevCamera cam, PathPool pool, DevPhotonMap pmGlobal,
+__global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene scArg, DevCamera cam, PathPool pool, DevPhotonMap pmGlobal,
                                                             DevPhotonMap pmCaustic, SegQ qIn, const uint32_t* __restrict__ queueIn,
                                                             uint32_t n, unsigned long long seed, int sBase, int S,
                                                             const int* __restrict__ pixels, uint2* spill) {
@@ -585,8 +590,9 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene sc, DevCame
     __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
     segq_load_table(qIn, qtab);
     __syncthreads();
+    const DevSceneT<XF> sc(scArg);
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, nThreads = gridDim.x * blockDim.x;
-    const LgScene g{sc, pmGlobal, pmCaustic, TravStack{&lds_stack[threadIdx.x], spill + gtid, nThreads}};
+    const LgSceneT<DevSceneT<XF>> g{sc, pmGlobal, pmCaustic, TravStack{&lds_stack[threadIdx.x], spill + gtid, nThreads}};
     unsigned long long rays = 0, shadows = 0;
     // Every lane is a small state machine: it holds one camera sample and its stack of pending calls (secondary rays and
     // the shadow queries of the Shade() just evaluated), and at most one ray in flight. The wave runs ONE kind of step per
@@ -769,13 +775,15 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene sc, DevCame
 
 // ShadeInfoAdapter::TraceSecondaryRay (ShadeInfoAdapter.h:94-231) for n directions from one shading point: the entry
 // point behind rtx_trace_secondary. out[i] = {colour, dist}.
-__global__ __launch_bounds__(TRAV_BLOCK) void legacy_secondary_kernel(DevScene sc, DevPhotonMap pmGlobal, DevPhotonMap pmCaustic,
+template <bool XF>
+__global__ __launch_bounds__(TRAV_BLOCK) void legacy_secondary_kernel(DevScene scArg, DevPhotonMap pmGlobal, DevPhotonMap pmCaustic,
                                                                       rtx_shade_point at, const float* __restrict__ dirs, uint32_t n,
                                                                       int recursive, int child, unsigned long long seed,
                                                                       float4* __restrict__ out, uint2* spill) {
     __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
+    const DevSceneT<XF> sc(scArg);
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, nThreads = gridDim.x * blockDim.x;
-    const LgScene g{sc, pmGlobal, pmCaustic, TravStack{&lds_stack[threadIdx.x], spill + gtid, nThreads}};
+    const LgSceneT<DevSceneT<XF>> g{sc, pmGlobal, pmCaustic, TravStack{&lds_stack[threadIdx.x], spill + gtid, nThreads}};
     for (uint32_t i = gtid; i < n; i += nThreads) {
         LgState st;
         st.L = mk3(0.0f);
@@ -805,8 +813,12 @@ void launch_legacy_secondary(const DevScene& sc, const LaunchCfg& cfg, const Dev
     if (!n) return;
     const uint32_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
     const uint32_t grid = need < (uint32_t)cfg.gridBlocks ? need : (uint32_t)cfg.gridBlocks;
-    hipLaunchKernelGGL(legacy_secondary_kernel, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, pmGlobal, pmCaustic, at, dirs, n,
-                       recursive, child, seed, out, cfg.spill);
+    if (sc.has_xf)
+        hipLaunchKernelGGL(legacy_secondary_kernel<true>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, pmGlobal, pmCaustic, at, dirs, n,
+                           recursive, child, seed, out, cfg.spill);
+    else
+        hipLaunchKernelGGL(legacy_secondary_kernel<false>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, pmGlobal, pmCaustic, at, dirs, n,
+                           recursive, child, seed, out, cfg.spill);
 }
 
 void launch_legacy(const DevScene& sc, const LaunchCfg& cfg, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pmGlobal,
@@ -815,6 +827,10 @@ void launch_legacy(const DevScene& sc, const LaunchCfg& cfg, const DevCamera& ca
     if (!n) return;
     const uint32_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
     const uint32_t grid = need < (uint32_t)cfg.gridBlocks ? need : (uint32_t)cfg.gridBlocks;
-    hipLaunchKernelGGL(legacy_kernel, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, cam, pool, pmGlobal, pmCaustic, qIn, queueIn, n,
-                       seed, sBase, S, pixels, cfg.spill);
+    if (sc.has_xf)
+        hipLaunchKernelGGL(legacy_kernel<true>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, cam, pool, pmGlobal, pmCaustic, qIn, queueIn,
+                           n, seed, sBase, S, pixels, cfg.spill);
+    else
+        hipLaunchKernelGGL(legacy_kernel<false>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, cam, pool, pmGlobal, pmCaustic, qIn, queueIn,
+                           n, seed, sBase, S, pixels, cfg.spill);
 }

@@ -158,12 +158,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
 #define SHADOW_REFILL_MIN 16
 #endif
 // useTransmittance: bit 0 = Visible() with transmittance (else VisibleSimple), bit 1 = no early exit (parity checks)
+template <bool XF>
 #ifdef SHADOW_WAVES_PER_EU
 __attribute__((amdgpu_waves_per_eu(SHADOW_WAVES_PER_EU)))
 #endif
-__global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene sc, PathPool pool, SegQ q, int useTransmittance, uint2* spill,
+__global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, PathPool pool, SegQ q, int useTransmittance, uint2* spill,
                                                             uint32_t chunk) {
     __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
+    const DevSceneT<XF> sc(scArg);
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
     TravStack st{&lds_stack[threadIdx.x], spill + gtid, gridDim.x * blockDim.x};
     uint32_t hops = 0;
@@ -468,8 +470,12 @@ void launch_shadow(const DevScene& sc, const LaunchCfg& cfg, const PathPool& poo
     if (!n) return;
     const uint32_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
     const uint32_t grid = need < (uint32_t)cfg.gridBlocks ? need : (uint32_t)cfg.gridBlocks;
-    hipLaunchKernelGGL(shadow_kernel, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, pool, q, useTransmittance, cfg.spill,
-                       segq_chunk(n, grid * (TRAV_BLOCK / 64)));
+    if (sc.has_xf)
+        hipLaunchKernelGGL(shadow_kernel<true>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, pool, q, useTransmittance, cfg.spill,
+                           segq_chunk(n, grid * (TRAV_BLOCK / 64)));
+    else
+        hipLaunchKernelGGL(shadow_kernel<false>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, pool, q, useTransmittance, cfg.spill,
+                           segq_chunk(n, grid * (TRAV_BLOCK / 64)));
 }
 void launch_film(const PathPool& pool, const rtx_film& film, const int* pixels, uint32_t nPix, int S, int W, int H, int filterType,
                  float filterRadius, int resetZ, float4* samplesOut, int sBase, int sppTotal, float radianceClamp, int nLights,

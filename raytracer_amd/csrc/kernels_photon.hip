@@ -7,14 +7,16 @@
 #include "shadow.h"
 #include "photon_gather.h"
 
+template <bool XF>
 #ifdef PHOTON_WAVES_PER_EU
 __attribute__((amdgpu_waves_per_eu(PHOTON_WAVES_PER_EU)))
 #endif
-__global__ __launch_bounds__(TRAV_BLOCK) void photon_emit_kernel(DevScene sc, int numPhotons, int first, int stride, int maxBounces,
+__global__ __launch_bounds__(TRAV_BLOCK) void photon_emit_kernel(DevScene scArg, int numPhotons, int first, int stride, int maxBounces,
                                                                  unsigned long long seed, DevPhotonRec* __restrict__ globalOut,
                                                                  uint32_t globalCap, DevPhotonRec* __restrict__ causticOut,
                                                                  uint32_t causticCap, uint32_t* counts, uint2* spill) {
     __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
+    const DevSceneT<XF> sc(scArg);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
     TravStack st{&lds_stack[threadIdx.x], spill + gtid, gridDim.x * blockDim.x};
@@ -164,8 +166,12 @@ void launch_photon_emit(const DevScene& sc, const LaunchCfg& cfg, int numPhotons
     if (!nWork) return;
     const uint32_t need = (nWork + TRAV_BLOCK - 1) / TRAV_BLOCK;
     const uint32_t grid = need < (uint32_t)cfg.gridBlocks ? need : (uint32_t)cfg.gridBlocks;
-    hipLaunchKernelGGL(photon_emit_kernel, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, numPhotons, first, stride, maxBounces, seed,
-                       g, gcap, c, ccap, counts, cfg.spill);
+    if (sc.has_xf)
+        hipLaunchKernelGGL(photon_emit_kernel<true>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, numPhotons, first, stride, maxBounces,
+                           seed, g, gcap, c, ccap, counts, cfg.spill);
+    else
+        hipLaunchKernelGGL(photon_emit_kernel<false>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, numPhotons, first, stride, maxBounces,
+                           seed, g, gcap, c, ccap, counts, cfg.spill);
 }
 void launch_photon_count(const PhotonSet& s, uint32_t* cellCount, hipStream_t st) {
     if (!s.n) return;

@@ -15,15 +15,16 @@
 #ifndef TAIL_REFILL_MIN
 #define TAIL_REFILL_MIN 2u   // idle quads of a wave before it fetches new paths
 #endif
-template <bool MICRO>
+template <bool MICRO, bool XF>
 #ifdef TAIL_WAVES_PER_EU
 __attribute__((amdgpu_waves_per_eu(TAIL_WAVES_PER_EU)))
 #endif
-__global__ __launch_bounds__(TRAV_BLOCK) void tail_kernel(DevScene sc, DevCamera cam, PathPool pool, DevPhotonMap pm, SegQ qIn,
+__global__ __launch_bounds__(TRAV_BLOCK) void tail_kernel(DevScene scArg, DevCamera cam, PathPool pool, DevPhotonMap pm, SegQ qIn,
                                                           const uint32_t* __restrict__ queueIn, int bounce0, int maxBounces,
                                                           unsigned long long seed, int sBase, int S, const int* __restrict__ pixels,
                                                           int usePhotons, uint2* spill, uint32_t chunk) {
     __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
+    const DevSceneT<XF> sc(scArg);
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, q = lane & 3u;
     const int quadBase = (int)(lane & ~3u);
@@ -148,10 +149,15 @@ void launch_tail(const DevScene& sc, const LaunchCfg& cfg, const DevCamera& cam,
     // paths reserved per atomic by a wave of 16 quads: small enough that every wave of the grid gets some
     uint32_t chunk = n / (grid * (TRAV_BLOCK / 64u) * 2u);
     chunk = chunk < 16u ? 16u : (chunk > 256u ? 256u : (chunk / 16u) * 16u);
-    if (hasMicrofacet)
-        hipLaunchKernelGGL(tail_kernel<true>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, cam, pool, pm, qIn, queueIn, bounce0,
-                           maxBounces, seed, sBase, S, pixels, usePhotons, cfg.spill, chunk);
-    else
-        hipLaunchKernelGGL(tail_kernel<false>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, cam, pool, pm, qIn, queueIn, bounce0,
-                           maxBounces, seed, sBase, S, pixels, usePhotons, cfg.spill, chunk);
+#define RTX_LAUNCH_TAIL(M, X)                                                                                                         \
+    hipLaunchKernelGGL((tail_kernel<M, X>), dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, cam, pool, pm, qIn, queueIn, bounce0, maxBounces, \
+                       seed, sBase, S, pixels, usePhotons, cfg.spill, chunk)
+    if (hasMicrofacet) {
+        if (sc.has_xf) RTX_LAUNCH_TAIL(true, true);
+        else RTX_LAUNCH_TAIL(true, false);
+    } else {
+        if (sc.has_xf) RTX_LAUNCH_TAIL(false, true);
+        else RTX_LAUNCH_TAIL(false, false);
+    }
+#undef RTX_LAUNCH_TAIL
 }

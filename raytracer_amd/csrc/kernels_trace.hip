@@ -66,12 +66,13 @@ void launch_segq_identity(const SegQ& q, uint32_t n, hipStream_t stream) {
 #ifndef EXTEND_WAVES_PER_EU
 #define EXTEND_WAVES_PER_EU 6
 #endif
-template <bool COUNT>
-__global__ __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(EXTEND_WAVES_PER_EU))) void extend_kernel(DevScene sc, const float4* __restrict__ rays, SegQ q,
+template <bool COUNT, bool XF>
+__global__ __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(EXTEND_WAVES_PER_EU))) void extend_kernel(DevScene scArg, const float4* __restrict__ rays, SegQ q,
                                                             const uint32_t* __restrict__ items, int hitSide, int withLights,
                                                             float4* __restrict__ hits, uint2* spill, unsigned long long* counters,
                                                             uint32_t chunk) {
     __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
+    const DevSceneT<XF> sc(scArg);
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
     TravStack st{&lds_stack[threadIdx.x], spill + gtid, gridDim.x * blockDim.x};
     uint32_t nodeCount = 0, triCount = 0, rayCount = 0;
@@ -154,12 +155,17 @@ void launch_extend_queue(const DevScene& sc, const LaunchCfg& cfg, const float4*
     const uint32_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
     const uint32_t grid = need < (uint32_t)cfg.gridBlocks ? need : (uint32_t)cfg.gridBlocks;
     const uint32_t chunk = segq_chunk(n, grid * (TRAV_BLOCK / 64));
-    if (cfg.counting)
-        hipLaunchKernelGGL(extend_kernel<true>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, rays, q, items, hitSide, withLights,
-                           hits, cfg.spill, cfg.counters, chunk);
-    else
-        hipLaunchKernelGGL(extend_kernel<false>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, rays, q, items, hitSide, withLights,
-                           hits, cfg.spill, cfg.counters, chunk);
+#define RTX_LAUNCH_EXTEND(C, X)                                                                                                  \
+    hipLaunchKernelGGL((extend_kernel<C, X>), dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, rays, q, items, hitSide, withLights, \
+                       hits, cfg.spill, cfg.counters, chunk)
+    if (cfg.counting) {
+        if (sc.has_xf) RTX_LAUNCH_EXTEND(true, true);
+        else RTX_LAUNCH_EXTEND(true, false);
+    } else {
+        if (sc.has_xf) RTX_LAUNCH_EXTEND(false, true);
+        else RTX_LAUNCH_EXTEND(false, false);
+    }
+#undef RTX_LAUNCH_EXTEND
 }
 void launch_extend(const DevScene& sc, const LaunchCfg& cfg, const float4* rays, uint32_t n, int hitSide, int withLights,
                    float4* hits) {
@@ -218,11 +224,8 @@ __global__ void expand_hits_kernel(DevScene sc, const float4* __restrict__ rays,
         o.mtl_id = s.mtlID;
         o.front = s.front ? 1 : 0;
         o.light = s.light;
-        // a mirrored object's triangles are baked with v1 and v2 exchanged (bvh_build.cpp): report the barycentrics in
-        // the caller's vertex order
-        const bool mirrored = s.obj >= 0 && (sc.objs[s.obj].flags & OBJ_MIRRORED) != 0u;
-        o.bu = mirrored ? h.v : h.u;
-        o.bv = mirrored ? h.u : h.v;
+        o.bu = h.u;
+        o.bv = h.v;
         o.p[0] = s.p.x; o.p[1] = s.p.y; o.p[2] = s.p.z;
         o.N[0] = s.N.x; o.N[1] = s.N.y; o.N[2] = s.N.z;
         o.GN[0] = s.GN.x; o.GN[1] = s.GN.y; o.GN[2] = s.GN.z;
@@ -239,12 +242,14 @@ void launch_expand_hits(const DevScene& sc, const float4* rays, const float4* hi
     hipLaunchKernelGGL(expand_hits_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sc, rays, hits, n, out);
 }
 
-__global__ __launch_bounds__(TRAV_BLOCK) void visibility_kernel(DevScene sc, const float4* __restrict__ rays,
+template <bool XF>
+__global__ __launch_bounds__(TRAV_BLOCK) void visibility_kernel(DevScene scArg, const float4* __restrict__ rays,
                                                                 const float4* __restrict__ normals, uint32_t n,
                                                                 int useTransmittance, float* __restrict__ vis,
                                                                 uint32_t* workCounter, uint2* spill,
                                                                 unsigned long long* hopCounter) {
     __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
+    const DevSceneT<XF> sc(scArg);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
     TravStack st{&lds_stack[threadIdx.x], spill + gtid, gridDim.x * blockDim.x};
@@ -271,15 +276,19 @@ void launch_visibility(const DevScene& sc, const LaunchCfg& cfg, const float4* r
     (void)hipMemsetAsync(cfg.workCounter, 0, sizeof(uint32_t), cfg.stream);
     const uint32_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
     const uint32_t grid = need < (uint32_t)cfg.gridBlocks ? need : (uint32_t)cfg.gridBlocks;
-    hipLaunchKernelGGL(visibility_kernel, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, rays, normals, n,
-                       useTransmittance, vis, cfg.workCounter, cfg.spill, hopCounter);
+    if (sc.has_xf)
+        hipLaunchKernelGGL(visibility_kernel<true>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, rays, normals, n, useTransmittance, vis,
+                           cfg.workCounter, cfg.spill, hopCounter);
+    else
+        hipLaunchKernelGGL(visibility_kernel<false>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, rays, normals, n, useTransmittance, vis,
+                           cfg.workCounter, cfg.spill, hopCounter);
 }
 
 int query_resident_blocks(int which) {
     int nb = 0;
     hipError_t e;
-    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, extend_kernel<false>, TRAV_BLOCK, 0);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, visibility_kernel, TRAV_BLOCK, 0);
+    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, extend_kernel<false, false>, TRAV_BLOCK, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, visibility_kernel<false>, TRAV_BLOCK, 0);
     if (e != hipSuccess || nb < 1) nb = 2;
     return nb;
 }

@@ -1,8 +1,9 @@
 // HBM data layout of the flattened scene (shared by the host builder and the HIP kernels).
 //
 // The reference keeps one pointer-based cy::BVHTriMesh per TriObj (objects.cpp:136, triobj_bvh.cpp:13-34) and
-// walks the scene graph per ray (IntersectNodeAdapter.h:23-97). Here all (Node,TriObj) pairs are baked into
-// world space and merged into ONE 4-wide BVH with quantised child boxes:
+// walks the scene graph per ray (IntersectNodeAdapter.h:23-97). Here all (Node,TriObj) pairs are merged into ONE
+// 4-wide BVH over world-space boxes with quantised child boxes (triangles of identity nodes are tested in world
+// space - every object of cerealBar.xml -, those of transformed nodes in their object space):
 //
 //   Node4   64 B   origin (3 x f32) + 3 power-of-two scales + 4 x (6 x u8 box) + 4 child references
 //   TriRec  48 B   v0, e1 = v1-v0, e2 = v2-v0 (the operands of objects.cpp:146-151) + global triangle id
@@ -41,13 +42,17 @@ struct TriRec {
     float v0x, v0y, v0z;
     uint32_t prim;          // global triangle id = faceBase[obj] + face (object order, then face order)
     float e1x, e1y, e1z;
-    uint32_t kind;          // 0 = triangle; RTX_OBJ_SPHERE / RTX_OBJ_PLANE: analytic object, then v0 = world box
-                            // min, e1 = e2 = box extent (so v0, v0+e1 span its box) and `obj` names its transform
+    uint32_t kind;          // 0 = triangle in world space (identity node transform); RTX_KIND_XFTRI = triangle of an object
+                            // under a non-identity node transform: v0, e1, e2 are the OBJECT-space operands and the ray
+                            // is carried to node coordinates for the test (`obj` names the transform), as
+                            // IntersectNodeAdapter.h:62,93 does; RTX_OBJ_SPHERE / RTX_OBJ_PLANE: analytic object, then
+                            // v0 = world box min, e1 = e2 = box extent (so v0, v0+e1 span its box)
     float e2x, e2y, e2z;
-    uint32_t obj;           // object index (read for analytic records only) | TRI_OPAQUE: the object's material lets no
+    uint32_t obj;           // object index (read for analytic and transformed records only) | TRI_OPAQUE: the object's material lets no
                             // light through (Visible() returns 0 at it). Kept out of `kind`, which the triangle test reads.
 };
 static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+#define RTX_KIND_XFTRI 3u
 #define TRI_OBJ_MASK 0x7FFFFFFFu
 #define TRI_OPAQUE 0x80000000u
 
@@ -60,15 +65,14 @@ static_assert(sizeof(TriAttr) == 64, "TriAttr must be 64 bytes");
 
 #define OBJ_HAS_NORMALS 1u
 #define OBJ_HAS_TEXCOORDS 2u
-#define OBJ_TRANSFORMED 8u   // the object's transform is not the identity (its triangles are baked to world space)
-#define OBJ_MIRRORED 4u   // the object's transform has a negative determinant: its triangles are baked with v1 and v2 exchanged
+#define OBJ_TRANSFORMED 8u   // the object's transform is not the identity: its triangles stay in object space (RTX_KIND_XFTRI)
 struct ObjRec {
     int material;           // index into materials, -1 = none
     uint32_t flags;
     int face_base;          // first global triangle id of this object
     int nf;
 };
-// object <-> world transforms (Node::ToNodeCoords / FromNodeCoords), used by analytic objects only
+// object <-> world transforms (Node::ToNodeCoords / FromNodeCoords), used by analytic objects and transformed meshes
 struct ObjXform {
     float fwd[12];          // object -> world, 3x4 row-major
     float inv[12];          // world -> object
@@ -116,4 +120,6 @@ struct DevScene {
     float env[3]; int env_tex;
     float bg[3];  int bg_tex;
     float bg_emission;
+    int has_xf;             // some mesh sits under a non-identity node transform (RTX_KIND_XFTRI records): selects the kernel
+                            // instantiations that carry the object-space triangle test (traverse.h DevSceneT)
 };

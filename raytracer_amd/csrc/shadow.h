@@ -16,9 +16,9 @@ __device__ __forceinline__ void triangle_gn(const DevScene& sc, const RayT& r, i
     const float4* tris4 = reinterpret_cast<const float4*>(sc.tris);
     const float4 b = tris4[(size_t)slot * 3 + 1];
     const float4 c = tris4[(size_t)slot * 3 + 2];
-    if (__float_as_uint(b.w) != 0u) {   // Sphere / Plane
+    if (__float_as_uint(b.w) != 0u) {   // Sphere / Plane / mesh under a node transform: through the object's space
         SurfHit sh;
-        resolve_analytic(sc, __float_as_uint(b.w), __float_as_uint(c.w) & TRI_OBJ_MASK, r, HitT{t, 0.0f, 0.0f, slot}, sh);
+        resolve_triangle(sc, r, HitT{t, 0.0f, 0.0f, slot}, sh);
         GN = sh.GN;
         front = sh.front;
         obj = sh.obj;
@@ -40,7 +40,12 @@ __device__ __forceinline__ bool shadow_hop_end(const DevScene& sc, f3& o, f3 d, 
     result = visibility;
     if (h.slot == -1) return true;   // nothing blocking
     if (h.slot <= -2) return true;   // hit the light itself
-    const f3 hp = o + d * h.t;
+    f3 hp = o + d * h.t;
+    if (sc.tris[h.slot].kind != 0u) {   // HitInfo::p comes back through the node transform (IntersectNodeAdapter.h:93)
+        SurfHit sh;
+        resolve_triangle(sc, RayT{o.x, o.y, o.z, d.x, d.y, d.z, maxDist}, HitT{h.t, 0.0f, 0.0f, h.slot}, sh);
+        hp = sh.p;
+    }
     const float dist = len3(hp - o);
     if (dist >= maxDist - 1e-4f) return true;
     result = 0.0f;
@@ -102,8 +107,8 @@ __device__ __forceinline__ bool shadow_hit_decides(const DevScene& sc, const Tra
 }
 
 // o = OffsetPoint(origin, normal, dir), d = SafeNormalize(dir) already applied (RayCaster.cpp:199)
-template <bool COUNT>
-__device__ __forceinline__ float visible_chain_from(const DevScene& sc, f3 o, f3 d, float maxDist, bool useTransmittance,
+template <bool COUNT, class SC>
+__device__ __forceinline__ float visible_chain_from(const SC& sc, f3 o, f3 d, float maxDist, bool useTransmittance,
                                                     TravStack st, uint32_t* hops, uint32_t* nodeCount, uint32_t* triCount) {
     float visibility = 1.0f, result = 1.0f;
     int hop = 0;
@@ -116,8 +121,8 @@ __device__ __forceinline__ float visible_chain_from(const DevScene& sc, f3 o, f3
     }
 }
 
-template <bool COUNT>
-__device__ __forceinline__ float visible_chain(const DevScene& sc, f3 origin, f3 normal, f3 dirIn, float maxDist,
+template <bool COUNT, class SC>
+__device__ __forceinline__ float visible_chain(const SC& sc, f3 origin, f3 normal, f3 dirIn, float maxDist,
                                                bool useTransmittance, TravStack st, uint32_t* hops, uint32_t* nodeCount,
                                                uint32_t* triCount) {
     return visible_chain_from<COUNT>(sc, offset_point(origin, normal, dirIn), safe_normalize3(dirIn), maxDist, useTransmittance,

@@ -120,9 +120,18 @@ __device__ __forceinline__ void resolve_triangle(const DevScene& sc, const RayT&
     const float4 a = tris4[(size_t)h.slot * 3 + 0];
     const float4 b = tris4[(size_t)h.slot * 3 + 1];
     const float4 c = tris4[(size_t)h.slot * 3 + 2];
-    if (__float_as_uint(b.w) != 0u) {
-        resolve_analytic(sc, __float_as_uint(b.w), __float_as_uint(c.w) & TRI_OBJ_MASK, r, h, s);
+    const uint32_t kind = __float_as_uint(b.w);
+    if (kind != 0u && kind != RTX_KIND_XFTRI) {
+        resolve_analytic(sc, kind, __float_as_uint(c.w) & TRI_OBJ_MASK, r, h, s);
         return;
+    }
+    // the ray in the triangle's own space: world for identity nodes, node coordinates otherwise (the HitInfo is then built
+    // in object space as objects.cpp:172-240 does and brought back by Node::FromNodeCoords, IntersectNodeAdapter.h:93)
+    RayT rr = r;
+    if (kind == RTX_KIND_XFTRI) {
+        float p[3], d[3];
+        ray_to_object(sc, __float_as_uint(c.w) & TRI_OBJ_MASK, r, p, d);
+        rr = RayT{p[0], p[1], p[2], d[0], d[1], d[2], r.tmax};
     }
     const float4* at4 = reinterpret_cast<const float4*>(sc.attrs + h.slot);
     const float4 q0 = at4[0], q1 = at4[1], q2 = at4[2], q3 = at4[3];
@@ -145,10 +154,10 @@ __device__ __forceinline__ void resolve_triangle(const DevScene& sc, const RayT&
         if (len2_3(N) > 0.0f) N = normalized3(N);
         else N = GN;
     }
-    const f3 dir = mk3(r.dx, r.dy, r.dz);
+    const f3 dir = mk3(rr.dx, rr.dy, rr.dz);
     s.front = dot3(dir, GN) < 0.0f;
     s.t = h.t;
-    s.p = mk3(r.ox, r.oy, r.oz) + dir * h.t;
+    s.p = mk3(rr.ox, rr.oy, rr.oz) + dir * h.t;
     s.GN = GN;
     s.N = N;
     s.obj = obj;
@@ -172,25 +181,6 @@ __device__ __forceinline__ void resolve_triangle(const DevScene& sc, const RayT&
     } else {
         s.uvw = mk3(0.0f);
     }
-#ifndef RTX_NO_TRANSFORMED_FRAME   // (variant builds: cost of this branch on scenes without transformed meshes)
-    if (o.flags & OBJ_TRANSFORMED) {
-        // The reference builds this fallback frame in object space, around the object-space geometric normal, and
-        // takes it to the world as vectors (objects.cpp:233-240, then Node::FromNodeCoords). GN = normalize(M^-T n)
-        // gives n back as normalize(M^T GN); the length test is on the object-space derivatives M^-1 dpdu.
-        const ObjXform& X = sc.objXf[obj];
-        const float* F = X.fwd;
-        if (len2_3(xf_vec3(X.inv, s.dpdu)) < RTX_EPS || len2_3(xf_vec3(X.inv, s.dpdv)) < RTX_EPS) {
-            const f3 n = normalized3(mk3(F[0] * GN.x + F[4] * GN.y + F[8] * GN.z, F[1] * GN.x + F[5] * GN.y + F[9] * GN.z,
-                                         F[2] * GN.x + F[6] * GN.y + F[10] * GN.z));
-            f3 tangent = (fabsf(n.x) > 0.5f) ? mk3(-n.y, n.x, 0.0f) : mk3(0.0f, -n.z, n.y);
-            tangent = normalized3(tangent);
-            f3 bitangent = cross3(n, tangent);
-            bitangent = normalized3(bitangent);
-            s.dpdu = xf_vec3(F, tangent);
-            s.dpdv = xf_vec3(F, bitangent);
-        }
-    } else
-#endif
     if (len2_3(s.dpdu) < RTX_EPS || len2_3(s.dpdv) < RTX_EPS) {
         f3 tangent = (fabsf(GN.x) > 0.5f) ? mk3(-GN.y, GN.x, 0.0f) : mk3(0.0f, -GN.z, GN.y);
         tangent = normalized3(tangent);
@@ -198,6 +188,18 @@ __device__ __forceinline__ void resolve_triangle(const DevScene& sc, const RayT&
         bitangent = normalized3(bitangent);
         s.dpdu = tangent;
         s.dpdv = bitangent;
+    }
+    if (kind == RTX_KIND_XFTRI) {   // Node::FromNodeCoords: p by the node transform, normals by the transposed inverse and renormalised
+        const ObjXform& X = sc.objXf[obj];
+        const float* F = X.fwd;
+        const float* I = X.inv;
+        s.p = xf_point3(F, s.p);
+        s.N = normalized3(mk3(I[0] * s.N.x + I[4] * s.N.y + I[8] * s.N.z, I[1] * s.N.x + I[5] * s.N.y + I[9] * s.N.z,
+                              I[2] * s.N.x + I[6] * s.N.y + I[10] * s.N.z));
+        s.GN = normalized3(mk3(I[0] * s.GN.x + I[4] * s.GN.y + I[8] * s.GN.z, I[1] * s.GN.x + I[5] * s.GN.y + I[9] * s.GN.z,
+                               I[2] * s.GN.x + I[6] * s.GN.y + I[10] * s.GN.z));
+        s.dpdu = xf_vec3(F, s.dpdu);
+        s.dpdv = xf_vec3(F, s.dpdv);
     }
 }
 

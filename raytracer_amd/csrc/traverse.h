@@ -152,11 +152,29 @@ __device__ __forceinline__ void test_analytic(const DevScene& sc, uint32_t kind,
     best.slot = (int)slot;
     bestPrim = prim;
 }
-__device__ __forceinline__ void test_primitive(const DevScene& sc, const float4 a, const float4 b, const float4 c, const RayT& r,
+// Scene argument of the traversal functions with one compile-time fact attached: whether the scene holds meshes under a
+// non-identity node transform (RTX_KIND_XFTRI records). Their test is a second inlined copy of the triangle test behind
+// a ray transform; merely compiling it into the traversal loop raises its register pressure (28 spilled VGPRs, extend
+// +68 % on scenes that hold no such mesh - every object of cerealBar.xml is an identity node), and as a non-inlined
+// call it costs more still. So the kernels exist in two instantiations and the launch wrappers pick by DevScene::has_xf.
+template <bool XF>
+struct DevSceneT : DevScene {
+    static constexpr bool kXF = XF;
+    __device__ __forceinline__ explicit DevSceneT(const DevScene& s) : DevScene(s) {}
+};
+template <class SC>
+__device__ __forceinline__ void test_primitive(const SC& sc, const float4 a, const float4 b, const float4 c, const RayT& r,
                                                int hitSide, uint32_t slot, HitT& best, uint32_t& bestPrim) {
     const uint32_t kind = __float_as_uint(b.w);
-    if (kind != 0u) test_analytic(sc, kind, __float_as_uint(c.w) & TRI_OBJ_MASK, __float_as_uint(a.w), r, hitSide, slot, best, bestPrim);
-    else test_triangle(a, b, c, r, hitSide, slot, sc.tris, best, bestPrim);
+    if (kind == 0u) test_triangle(a, b, c, r, hitSide, slot, sc.tris, best, bestPrim);
+    else if (SC::kXF && kind == RTX_KIND_XFTRI) {
+        // a mesh under a non-identity node transform: the ray goes to node coordinates (direction not renormalised, so t
+        // is the same parameter) and meets the object's own fp32 vertices (IntersectNodeAdapter.h:62 -> objects.cpp:140)
+        float p[3], d[3];
+        ray_to_object(sc, __float_as_uint(c.w) & TRI_OBJ_MASK, r, p, d);
+        test_triangle(a, b, c, RayT{p[0], p[1], p[2], d[0], d[1], d[2], r.tmax}, hitSide, slot, sc.tris, best, bestPrim);
+    } else
+        test_analytic(sc, kind, __float_as_uint(c.w) & TRI_OBJ_MASK, __float_as_uint(a.w), r, hitSide, slot, best, bestPrim);
 }
 
 // ---- traversal as a small state machine -------------------------------------------------------------------
@@ -290,7 +308,8 @@ __device__ __forceinline__ void trav_inner_step(TravState& s, const DevScene& sc
 }
 
 // The records of one leaf reference (consecutive 48-byte records). Returns the number tested.
-__device__ __forceinline__ uint32_t trav_leaf_test(TravState& s, const DevScene& sc, uint32_t ref, int hitSide) {
+template <class SC>
+__device__ __forceinline__ uint32_t trav_leaf_test(TravState& s, const SC& sc, uint32_t ref, int hitSide) {
     const float4* tris4 = reinterpret_cast<const float4*>(sc.tris);
     const uint32_t first = (ref & 0x7FFFFFFFu) >> 3;
     const uint32_t cnt = (ref & 7u) + 1u;
@@ -304,7 +323,8 @@ __device__ __forceinline__ uint32_t trav_leaf_test(TravState& s, const DevScene&
     return cnt;
 }
 // One leaf: test it, then continue with the next subtree on the stack.
-__device__ __forceinline__ uint32_t trav_leaf_step(TravState& s, const DevScene& sc, TravStack& st, int hitSide) {
+template <class SC>
+__device__ __forceinline__ uint32_t trav_leaf_step(TravState& s, const SC& sc, TravStack& st, int hitSide) {
     const uint32_t cnt = trav_leaf_test(s, sc, s.cur, hitSide);
     trav_pop(s, st);
     return cnt;
@@ -312,8 +332,8 @@ __device__ __forceinline__ uint32_t trav_leaf_step(TravState& s, const DevScene&
 
 // Closest hit along r within (EPS, r.tmax), run to completion by one lane (shadow chains, photons).
 // counters (optional): [0] += nodes visited, [1] += triangles tested.
-template <bool COUNT>
-__device__ __forceinline__ HitT traverse_closest(const DevScene& sc, const RayT& r, int hitSide, TravStack st,
+template <bool COUNT, class SC>
+__device__ __forceinline__ HitT traverse_closest(const SC& sc, const RayT& r, int hitSide, TravStack st,
                                                  uint32_t* nodeCount, uint32_t* triCount) {
     TravState s;
     trav_init(s, sc, r);

@@ -92,11 +92,14 @@ def test_transformed_instances(rtx):
     rays = random_rays(np.random.default_rng(3), 20000, osc.bounds())
     g = gs.trace_closest(rays, _ffi.HIT_FRONT_AND_BACK)
     o = osc.trace_closest(rays, _ffi.HIT_FRONT_AND_BACK)
-    # world-space baking rounds differently from the reference's per-node ray transform: 1e-4 on t
-    same, hit = compare_hits(g, o, gs.face_base, id_tol=2e-3, t_rel=1e-4)
-    n_g = g["N"][hit] / np.linalg.norm(g["N"][hit], axis=1, keepdims=True)
-    n_o = o["N"][hit] / np.linalg.norm(o["N"][hit], axis=1, keepdims=True)
-    assert np.abs(n_g - n_o).max() < 1e-3
+    # the ray is carried to node coordinates and meets the object's own vertices, as in the reference: the north_star
+    # bar (ids >= 99.99 %, t within 1e-5) holds under transforms too; measured: every id equal, t bit-identical
+    same, hit = compare_hits(g, o, gs.face_base)
+    assert same.all() and np.array_equal(g["t"][hit], o["t"][hit])
+    assert np.array_equal(g["bu"][hit], o["bu"][hit]) and np.array_equal(g["bv"][hit], o["bv"][hit])
+    for f in ("N", "GN", "p", "uvw", "dpdu", "dpdv"):
+        assert np.abs(g[f][hit] - o[f][hit]).max() <= 1e-5 * max(1.0, np.abs(o[f][hit]).max()), f
+    assert (g["front"][hit] == o["front"][hit]).all()
 
 
 def test_degenerate_directions(c1):

@@ -46,10 +46,10 @@ def test_mirrored_transform_closest_hit(rtx, with_normals):
         hit = o["obj"] >= 0
         assert hit.sum() > 50 or side == _ffi.HIT_BACK
         same = (g["obj"] == o["obj"]) & (g["face"] == o["face"])
-        assert same.mean() >= 0.995                                    # object-space vs world-space edges: a grazed edge may differ
+        assert same.mean() >= 0.9999                                   # object-space test on both sides: north_star bar
         k = same & hit
         assert (g["front"][k] == o["front"][k]).all()
-        assert np.allclose(g["t"][k], o["t"][k], rtol=2e-5)
+        assert np.allclose(g["t"][k], o["t"][k], rtol=1e-5)
         for f in ("GN", "N"):
             assert np.abs(g[f][k] - o[f][k]).max() <= 2e-5, f
         assert np.abs(g["bu"][k] - o["bu"][k]).max() <= 2e-4 and np.abs(g["bv"][k] - o["bv"][k]).max() <= 2e-4
@@ -140,6 +140,6 @@ def test_duplicate_faces_tie_rule(rtx):
         ob = osc.trace_closest(rays, hit_side=side, use_bvh=False)
         assert (o["face"] == ob["face"]).all() and (o["obj"] == ob["obj"]).all()
         same = (g["obj"] == o["obj"]) & (g["face"] == o["face"]) & (g["mtl_id"] == o["mtl_id"])
-        assert same.mean() >= 0.995
+        assert same.mean() >= 0.9999
         hit = g["obj"] >= 0
         assert (g["obj"][hit] == 0).all() and (g["face"][hit] < 12).all()
