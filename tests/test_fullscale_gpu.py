@@ -1,4 +1,4 @@
-"""Full-size checks at BASELINE.json's sizes (6.6 M triangles, 1920x1080) through properties that need no oracle run:
+"""Full-size checks at BASELINE.json's sizes (6.6 M triangles, 1920x1080): properties that need no oracle run -
 hit ordering/idempotence of the closest hit, tile-sharding additivity, and image sanity of a path-traced frame."""
 import numpy as np
 import pytest
@@ -89,3 +89,62 @@ def test_sharded_frame_adds_up_full_size(full, rtx):
     assert float(w.min()) > 0 and torch.isfinite(full_t[0]).all()
     lin = full_t[0][:, :3] / w[:, None]
     assert 0.05 < float(lin.mean()) < 5.0 and float(lin.max()) <= 10.0 + 1e-3
+
+
+# ---- the oracle at full size: a seeded subset of the 1080p frame and random rays on the full BVH --------------------
+# Everything above is oracle-free; here the CPU oracle builds its own BVHs over the same 6.57 M triangles (seconds)
+# and traces a random subset of what the GPU traced, so the deep-tree paths of the traversal (stack entries beyond the
+# 12 kept in LDS spill to the global slab) are compared with something.
+
+@pytest.fixture(scope="module")
+def full_oracle(full):
+    from tests.oracle_ffi import OracleScene
+    return OracleScene(full[0])
+
+
+def test_full_size_closest_hit_against_oracle(full, full_oracle):
+    from tests.helpers import random_rays, compare_hits
+    sd, gs, cam = full
+    rng = np.random.default_rng(77)
+    rays = random_rays(rng, 200000, full_oracle.bounds())
+    for side in (_ffi.HIT_FRONT_AND_BACK, _ffi.HIT_FRONT):
+        g = gs.trace_closest(rays, side, with_lights=True)
+        o = full_oracle.trace_closest(rays, side, with_lights=True)
+        same, hit = compare_hits(g, o, gs.face_base)                  # ids >= 99.99 %, t within 1e-5
+        assert hit.mean() > 0.3
+        assert np.array_equal(g["t"][hit], o["t"][hit])                # measured: bit-identical
+        assert np.array_equal(g["bu"][hit], o["bu"][hit]) and np.array_equal(g["bv"][hit], o["bv"][hit])
+
+
+def test_full_size_path_samples_against_oracle(full, full_oracle):
+    """The benchmark's own frame (1920x1080, 64 bounces) at 4 spp: per-sample radiance of 4096 random pixels x 4 samples
+    against the oracle. Direct lighting (max_bounces 1) holds the bar of tests/test_path_gpu.py; for the 64-bounce loop
+    the share of samples that agree falls with the scene's size - 99.8 % at 20 k triangles, 99.3 % at 130 k, 94.7 % here
+    (tools/fullsize_diag.py: 100 % / 99.98 % / 99.5 % / 97.1 % / 94.7 % at max_bounces 1 / 2 / 4 / 8 / 64): the 6.57 M
+    triangles are mostly millimetre-sized cereal tori and spheres, and a bounce off a surface of radius r seen from
+    distance d multiplies a direction error by ~d/r, so the last-bit difference between the GPU's and glibc's
+    powf / sinf / cosf is a different path a few bounces later. Such samples differ by O(1), not by 1e-3, and without
+    bias: the means of the two sample sets must agree within their noise."""
+    sd, gs, cam = full
+    spp = 4
+    rp = render_params(spp_min=spp, max_bounces=64)
+    g, st = gs.render_samples(cam, rp)
+    assert st["rays_primary"] == cam.width * cam.height * spp
+    rng = np.random.default_rng(78)
+    k = 4096
+    px, py = rng.integers(0, cam.width, k), rng.integers(0, cam.height, k)
+    xys = np.stack([np.repeat(px, spp), np.repeat(py, spp), np.tile(np.arange(spp), k)], 1).astype(np.int32)
+    o = full_oracle.trace_samples(cam, rp, xys)
+    gsub = g[xys[:, 1], xys[:, 0], xys[:, 2]]
+    assert (np.abs(gsub[:, 3] - o[:, 3]) <= 1e-5 * np.abs(o[:, 3])).mean() >= 0.9999       # primary distance
+    d = np.abs(gsub[:, :3] - o[:, :3]).max(-1)
+    ref = 1 + np.abs(o[:, :3]).max(-1)
+    assert (d <= 1e-4 * ref).mean() >= 0.93, (d <= 1e-4 * ref).mean()
+    assert (o[:, :3].max(-1) > 0).mean() > 0.5
+    diff = (gsub[:, :3] - o[:, :3]).mean(-1).astype(np.float64)
+    assert abs(diff.mean()) <= 4.0 * diff.std() / np.sqrt(len(diff)) + 1e-6, (diff.mean(), diff.std())
+    rp1 = render_params(spp_min=spp, max_bounces=1)
+    g1, _ = gs.render_samples(cam, rp1)
+    o1 = full_oracle.trace_samples(cam, rp1, xys)
+    d1 = np.abs(g1[xys[:, 1], xys[:, 0], xys[:, 2]][:, :3] - o1[:, :3]).max(-1)
+    assert (d1 <= 1e-5 * (1 + np.abs(o1[:, :3]).max(-1))).mean() >= 0.9999
