@@ -107,6 +107,8 @@ typedef struct {
     float refraction[3]; int refraction_tex;
     float emission[3];   int emission_tex;
     float glossiness;
+    int glossiness_tex;            /* TexturedFloat map of Glossiness() (Shading.cpp:238 sInfo.Eval(mtl.Glossiness()),
+                                      Shading_Legacy.cpp:375): value * red channel of the texel; -1 = none */
     float ior;
     float absorption[3];           /* Beer-Lambert coefficients, RayCaster.cpp:281-301 */
     int bump_tex;                  /* BumpMapping.h:19, -1 = none                    */

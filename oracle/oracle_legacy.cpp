@@ -300,7 +300,7 @@ static bool generate_sample_legacy(const LegacyCtx& c, const Material& m, const 
     float total = diffWeight + reflWeight + refrWeight;
     if (total < 1e-6f) return false;
     float pick = s.rnd(DIM_LOBE) * total;
-    const float alpha = m.d.glossiness;
+    const float alpha = sc.eval_tf(m.d.glossiness, m.d.glossiness_tex, s.uvw);   // sInfo.Eval(Glossiness())
     if (pick < diffWeight) {
         V3 U, Vb;
         build_onb(N, U, Vb);
@@ -399,7 +399,7 @@ static V3 shade(const LegacyCtx& c, const Material& m, const LegacyInfo& li) {
     if (!s.front) N = -N;
     const V3 V = normalized(s.V);
     const V3 I = -V;
-    const float alpha = m.d.glossiness;
+    const float alpha = sc.eval_tf(m.d.glossiness, m.d.glossiness_tex, s.uvw);   // sInfo.Eval(Glossiness())
     const V3 kd = sc.eval_tc(m.d.diffuse, m.d.diffuse_tex, s.uvw);
     const V3 ks = sc.eval_tc(m.d.specular, m.d.specular_tex, s.uvw);
 

@@ -159,6 +159,11 @@ struct Scene {
         if (tex >= 0) return c * texmaps[tex].eval(uvw);
         return c;
     }
+    // TexturedFloat::Eval stand-in (texture.h is absent): value * red channel of the texel
+    float eval_tf(float value, int tex, V3 uvw) const {
+        if (tex >= 0) return value * texmaps[tex].eval(uvw).x;
+        return value;
+    }
 };
 
 Scene* scene_from_desc(const rtx_scene_desc* d);

@@ -307,7 +307,7 @@ static PhongCtx build_ctx(const Scene& sc, const rtx_material_desc& m, const SIn
     c.ks = sc.eval_tc(m.specular, m.specular_tex, s.uvw);
     c.kr = sc.eval_tc(m.reflection, m.reflection_tex, s.uvw);
     c.kt = sc.eval_tc(m.refraction, m.refraction_tex, s.uvw);
-    c.alpha = std::max(0.001f, m.glossiness);
+    c.alpha = std::max(0.001f, sc.eval_tf(m.glossiness, m.glossiness_tex, s.uvw));   // Shading.cpp:238
     c.ior = m.ior;
     c.kd = clamp_max(c.kd, 1.0f);
     c.ks = clamp_max(c.ks, 1.0f);

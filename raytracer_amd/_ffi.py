@@ -36,7 +36,7 @@ class MaterialDesc(C.Structure):
                 ("reflection", C.c_float * 3), ("reflection_tex", C.c_int),
                 ("refraction", C.c_float * 3), ("refraction_tex", C.c_int),
                 ("emission", C.c_float * 3), ("emission_tex", C.c_int),
-                ("glossiness", C.c_float), ("ior", C.c_float), ("absorption", C.c_float * 3),
+                ("glossiness", C.c_float), ("glossiness_tex", C.c_int), ("ior", C.c_float), ("absorption", C.c_float * 3),
                 ("bump_tex", C.c_int), ("bump_scale", C.c_float)]
 
 

@@ -71,7 +71,7 @@ __device__ __forceinline__ PhongCtx build_phong_ctx(const DevScene& sc, const De
     c.ks = eval_tc(sc, m.ks, m.ks_tex, s.uvw);
     c.kr = eval_tc(sc, m.kr, m.kr_tex, s.uvw);
     c.kt = eval_tc(sc, m.kt, m.kt_tex, s.uvw);
-    c.alpha = fmaxf(0.001f, m.gloss);
+    c.alpha = fmaxf(0.001f, eval_tf(sc, m.gloss, m.gloss_tex, s.uvw));
     c.ior = m.ior;
     c.kd = clamp_max3(c.kd, 1.0f);
     c.ks = clamp_max3(c.ks, 1.0f);

@@ -310,7 +310,7 @@ __device__ __forceinline__ bool lg_generate_sample(const DevScene& sc, const Dev
     const float total = diffWeight + reflWeight + refrWeight;
     if (total < 1e-6f) return false;
     const float pick = s.rnd(DIM_LOBE) * total;
-    const float alpha = m.gloss;
+    const float alpha = eval_tf(sc, m.gloss, m.gloss_tex, s.uvw);
     if (pick < diffWeight) {
         f3 U, Vb;
         build_onb(N, U, Vb);
@@ -411,7 +411,7 @@ __device__ __forceinline__ void lg_shade(const G& g, const DevMaterial& m, const
     if (!sx.front) N = -N;
     const f3 V = normalized3(sx.V);
     const f3 I = -V;
-    const float alpha = m.gloss;
+    const float alpha = eval_tf(sc, m.gloss, m.gloss_tex, sx.uvw);
     const f3 kd = eval_tc(sc, m.kd, m.kd_tex, sx.uvw);
     const f3 ks = eval_tc(sc, m.ks, m.ks_tex, sx.uvw);
 

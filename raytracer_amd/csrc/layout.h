@@ -92,6 +92,7 @@ struct DevMaterial {
     float kt[3]; int kt_tex;
     float ke[3]; int ke_tex;
     float gloss, ior;
+    int gloss_tex;
     float absorption[3];
     int bump_tex;
     float bump_scale;

@@ -190,7 +190,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     for (int i = 0; i < desc->n_materials; ++i) {
         const rtx_material_desc& m = desc->materials[i];
         if (!texOK(m.diffuse_tex) || !texOK(m.specular_tex) || !texOK(m.reflection_tex) || !texOK(m.refraction_tex) ||
-            !texOK(m.emission_tex) || !texOK(m.bump_tex) || (m.type != RTX_MTL_BLINN && m.type != RTX_MTL_PHONG && m.type != RTX_MTL_MICROFACET)) {
+            !texOK(m.emission_tex) || !texOK(m.bump_tex) || !texOK(m.glossiness_tex) || (m.type != RTX_MTL_BLINN && m.type != RTX_MTL_PHONG && m.type != RTX_MTL_MICROFACET)) {
             rtx_scene_destroy(s);
             return rtx_fail(RTX_ERR_INVALID, "material " + std::to_string(i) + ": bad texture index or type");
         }
@@ -203,6 +203,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
         std::memcpy(o.kt, m.refraction, 12); o.kt_tex = m.refraction_tex;
         std::memcpy(o.ke, m.emission, 12);   o.ke_tex = m.emission_tex;
         o.gloss = m.glossiness;
+        o.gloss_tex = m.glossiness_tex;
         o.ior = m.ior;
         std::memcpy(o.absorption, m.absorption, 12);
         o.bump_tex = m.bump_tex;

@@ -71,6 +71,12 @@ __device__ __forceinline__ f3 eval_tc(const DevScene& sc, const float* value, in
     return c;
 }
 
+// TexturedFloat::Eval stand-in (the framework's texture.h is absent): value * red channel of the texel
+__device__ __forceinline__ float eval_tf(const DevScene& sc, float value, int tex, f3 uvw) {
+    if (tex >= 0) return value * tex_eval(sc, tex, uvw).x;
+    return value;
+}
+
 // HitInfo of a Sphere / Plane hit (objects.cpp:47-85, :100-125) followed by Node::FromNodeCoords
 // (IntersectNodeAdapter.h:93; framework convention as in the oracle: p by the node transform, normals by the
 // transposed inverse and renormalised, dpdu/dpdv as vectors).

@@ -110,6 +110,7 @@ private:
             color(d.refraction, m->refraction.value); d.refraction_tex = tex.Get(m->refraction.map.get());
             color(d.emission, m->emission.value);     d.emission_tex = tex.Get(m->emission.map.get());
             d.glossiness = m->glossiness;
+            d.glossiness_tex = tex.Get(m->glossinessMap.get());
             d.ior = m->ior;
             color(d.absorption, m->absorption);
             d.bump_tex = tex.Get(m->bump.get());

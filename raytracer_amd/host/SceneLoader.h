@@ -470,7 +470,10 @@ private:
                 ReadTexturedColor(c, m->refraction, false);
                 m->ior = c.Float("index", m->ior);
             } else if (c.name == "emission") ReadTexturedColor(c, m->emission, false);
-            else if (c.name == "glossiness") m->glossiness = c.Float("value", m->glossiness);
+            else if (c.name == "glossiness") {
+                m->glossiness = c.Float("value", m->glossiness);
+                if (c.Has("texture")) m->glossinessMap = GetTexture(c.Str("texture"));
+            }
             else if (c.name == "absorption") m->absorption = ReadColor(c, Color(0, 0, 0));
             else if (c.name == "bump") {
                 if (c.Has("texture")) m->bump = GetTexture(c.Str("texture"));

@@ -123,6 +123,7 @@ public:
     virtual int Type() const = 0;
     TexturedColor diffuse, specular, reflection, refraction, emission;
     float glossiness = 20.0f, ior = 1.5f;
+    std::shared_ptr<TextureMap> glossinessMap;   // TexturedFloat Glossiness(): value * red channel of the map (Shading.cpp:238)
     Color absorption{0, 0, 0};
     std::shared_ptr<TextureMap> bump;
     float bumpIntensity = 1.0f;

@@ -47,7 +47,7 @@ class Material:
     def __init__(self, name="", type=_ffi.MTL_BLINN, diffuse=(0.5, 0.5, 0.5), specular=(0.7, 0.7, 0.7),
                  reflection=(0, 0, 0), refraction=(0, 0, 0), emission=(0, 0, 0), glossiness=20.0, ior=1.5,
                  absorption=(0, 0, 0), diffuse_tex=-1, specular_tex=-1, reflection_tex=-1, refraction_tex=-1,
-                 emission_tex=-1, bump_tex=-1, bump_scale=1.0):
+                 emission_tex=-1, bump_tex=-1, bump_scale=1.0, glossiness_tex=-1):
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -121,7 +121,7 @@ class SceneData:
             d.type = m.type
             for k in ("diffuse", "specular", "reflection", "refraction", "emission", "absorption"):
                 setattr(d, k, (C.c_float * 3)(*[float(x) for x in getattr(m, k)]))
-            for k in ("diffuse_tex", "specular_tex", "reflection_tex", "refraction_tex", "emission_tex", "bump_tex"):
+            for k in ("diffuse_tex", "specular_tex", "reflection_tex", "refraction_tex", "emission_tex", "bump_tex", "glossiness_tex"):
                 setattr(d, k, int(getattr(m, k)))
             d.glossiness, d.ior, d.bump_scale = float(m.glossiness), float(m.ior), float(m.bump_scale)
         texs = (_ffi.TexMapDesc * max(1, len(self.texmaps)))()

@@ -137,7 +137,7 @@ int main() {
         const Color* src[5] = {&m.diffuse.value, &m.specular.value, &m.reflection.value, &m.refraction.value, &m.emission.value};
         float* dst[5] = {d.diffuse, d.specular, d.reflection, d.refraction, d.emission};
         for (int k = 0; k < 5; ++k) { dst[k][0] = src[k]->r; dst[k][1] = src[k]->g; dst[k][2] = src[k]->b; }
-        d.diffuse_tex = d.specular_tex = d.reflection_tex = d.refraction_tex = d.emission_tex = d.bump_tex = -1;
+        d.diffuse_tex = d.specular_tex = d.reflection_tex = d.refraction_tex = d.emission_tex = d.bump_tex = d.glossiness_tex = -1;
         d.glossiness = m.glossiness; d.ior = m.ior; d.bump_scale = 1;
         d.absorption[0] = m.absorption.r; d.absorption[1] = m.absorption.g; d.absorption[2] = m.absorption.b;
     };

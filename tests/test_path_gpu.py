@@ -183,3 +183,21 @@ def test_scheduling_switches_do_not_change_results(small, monkeypatch):
     loop, _ = gs.render_samples(cam, rp)
     monkeypatch.delenv("RTX_AMD_TAIL_PATHS")
     assert np.array_equal(loop, base)
+
+
+@pytest.mark.parametrize("mode", [_ffi.SHADING_PATH, _ffi.SHADING_LEGACY])
+def test_textured_glossiness(rtx, mode):
+    """Glossiness() is a TexturedFloat in the reference (Shading.cpp:238, Shading_Legacy.cpp:375: sInfo.Eval(Glossiness())):
+    rtx_material_desc::glossiness_tex scales the value by the map's red channel, in both shading modes."""
+    sd = synth.build_scene(0.003)
+    cam = synth.cerealbar_camera(96, 54)
+    rp = render_params(spp_min=4, max_bounces=4, shading_mode=mode)
+    plain, _ = rtx.Scene(sd).render_samples(cam, rp)
+    for m in sd.materials:
+        if m.glossiness > 50.0 and m.glossiness < 1e4:
+            m.glossiness_tex = 0                              # the value-noise map the cereal materials use for bump
+    gs, osc = rtx.Scene(sd), OracleScene(sd)
+    g, _ = gs.render_samples(cam, rp)
+    o = osc.render_samples(cam, rp)
+    assert frac_within(g, o) >= 0.995 and frac_within(g, o, 1e-3) >= 0.997
+    assert np.abs(g[..., :3] - plain[..., :3]).mean() > 1e-4   # the map does change the highlights
