@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--max-bounces", type=int, default=64)
     ap.add_argument("--samples-per-pass", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=96)
+    ap.add_argument("--cpu-spp", type=int, default=0, help="samples per pixel of the CPU baseline (0 = the benchmark's own --spp)")
     ap.add_argument("--legacy", action="store_true",
                     help="legacy shading mode (SHADING_USE_LEGACY=1) instead of the headline path-traced configuration")
     return ap.parse_args()
@@ -240,16 +240,19 @@ def cpu_baseline(sd, cam, a):
     """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample of the
     same workload: every 8th 16x16 bucket in x and y at a reduced sample count."""
     from tests.oracle_ffi import OracleScene
-    threads = min(16, os.cpu_count() or 1)
+    # every host core this job may use: the GPU box exports its CPU share as OMP_NUM_THREADS (os.cpu_count() there is the
+    # whole machine, most of which belongs to other jobs)
+    threads = int(os.environ.get("OMP_NUM_THREADS") or 0) or (os.cpu_count() or 1)
+    cpu_spp = a.cpu_spp if a.cpu_spp > 0 else a.spp
     t0 = time.perf_counter()
     osc = OracleScene(sd)
     build_s = time.perf_counter() - t0
-    rp = render_params(spp_min=a.cpu_spp, max_bounces=a.max_bounces,
+    rp = render_params(spp_min=cpu_spp, max_bounces=a.max_bounces,
                        shading_mode=_ffi.SHADING_LEGACY if a.legacy else _ffi.SHADING_PATH)
     r = osc.render(cam, rp, nthreads=threads, subset_stride=8)
     rays = r["rays"]["primary"] + r["rays"]["bounce"] + r["rays"]["shadow"]
-    return {"value": rays / r["seconds"] / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"every 8th 16x16 bucket in x and y (1/64 of the frame) at {a.cpu_spp} spp, same scene/camera/sampler; "
+    return {"value": rays / r["seconds"] / 1e6, "unit": "Mrays/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": f"every 8th 16x16 bucket in x and y (1/64 of the frame) at {cpu_spp} spp, same scene/camera/sampler; "
                       f"{rays} ray segments in {r['seconds']:.2f} s (+{build_s:.1f} s BVH build, untimed)",
             "seconds": r["seconds"], "paths": r["rays"]["primary"]}
 

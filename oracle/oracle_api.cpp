@@ -322,3 +322,21 @@ int orc_photon_estimate(void* p, int which, const float* pos, const float* nrm, 
 }
 
 }  // extern "C"
+
+// The shared elementary functions (raytracer_amd/csrc/rtx_math.h) as this CPU build evaluates them: fn 0 powf(x, y),
+// 1 expf, 2 sinf, 3 cosf, 4 tanf, 5 asinf, 6 acosf, 7 atan2f(x, y). tests/test_math_*.py hold them to float64 and, bit
+// for bit, to the GPU's evaluation of the same source.
+extern "C" void orc_math(int fn, const float* x, const float* y, size_t n, float* out) {
+    for (size_t i = 0; i < n; ++i) {
+        switch (fn) {
+            case 0: out[i] = rtx_powf(x[i], y[i]); break;
+            case 1: out[i] = rtx_expf(x[i]); break;
+            case 2: out[i] = rtx_sinf(x[i]); break;
+            case 3: out[i] = rtx_cosf(x[i]); break;
+            case 4: out[i] = rtx_tanf(x[i]); break;
+            case 5: out[i] = rtx_asinf(x[i]); break;
+            case 6: out[i] = rtx_acosf(x[i]); break;
+            default: out[i] = rtx_atan2f(x[i], y[i]); break;
+        }
+    }
+}

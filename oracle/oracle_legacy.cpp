@@ -128,12 +128,12 @@ static V3 illuminate(const LegacyCtx& c, const LegacyInfo& li, const Light& ligh
         float h3 = halton(sIdx + 1, 3);
         h3 = h3 + jy;
         h3 -= std::floor(h3);
-        float gamma = std::asin(light.size / distC);
+        float gamma = rtx_asinf(light.size / distC);
         float u1 = h2, u2 = h3;
-        float cosTheta = 1.0f - u1 * (1.0f - std::cos(gamma));
+        float cosTheta = 1.0f - u1 * (1.0f - rtx_cosf(gamma));
         float sinTheta = std::sqrt(std::max(0.0f, 1.0f - cosTheta * cosTheta));
         float phi = 2.0f * PI_F * u2;
-        V3 sampleDir = normalized(U * std::cos(phi) * sinTheta + V * std::sin(phi) * sinTheta + L * cosTheta);
+        V3 sampleDir = normalized(U * rtx_cosf(phi) * sinTheta + V * rtx_sinf(phi) * sinTheta + L * cosTheta);
         float vis = trace_shadow_ray(c, li, sampleDir * distC, 1.0f);
         ++n;
         if (vis >= 0.999f) ++lit;
@@ -178,9 +178,9 @@ static float fresnel_exact(V3 I, V3 N, float ior) {
 static inline V3 apply_absorption_legacy(V3 c, V3 absorption, float dist) {
     if (dist <= 0.0f) return c;
     if (absorption.x == 0.0f && absorption.y == 0.0f && absorption.z == 0.0f) return c;
-    const float ar = std::exp(-absorption.x * dist);
-    const float ag = std::exp(-absorption.y * dist);
-    const float ab = std::exp(-absorption.z * dist);
+    const float ar = rtx_expf(-absorption.x * dist);
+    const float ag = rtx_expf(-absorption.y * dist);
+    const float ab = rtx_expf(-absorption.z * dist);
     return V3(c.x * ar, c.y * ag, c.z * ab);
 }
 
@@ -258,10 +258,10 @@ static V3 sample_glossy(const LegacyCtx& c, const LegacyInfo& li, V3 axis, float
     build_onb(axis, U, Vb);
     const int d0 = isReflection ? LG_DIM_REFL : LG_DIM_REFR;
     float u1 = li.s.rnd(d0), u2 = li.s.rnd(d0 + 1);
-    float cosTheta = std::pow(u1, 1.0f / (alpha + 1.0f));
+    float cosTheta = rtx_powf(u1, 1.0f / (alpha + 1.0f));
     float sinTheta = std::sqrt(std::max(0.0f, 1.0f - cosTheta * cosTheta));
     float phi = 2.0f * PI_F * u2;
-    V3 H = normalized(U * std::cos(phi) * sinTheta + Vb * std::sin(phi) * sinTheta + axis * cosTheta);
+    V3 H = normalized(U * rtx_cosf(phi) * sinTheta + Vb * rtx_sinf(phi) * sinTheta + axis * cosTheta);
     V3 dir = isReflection ? (2.0f * dot(V, H) * H - V) : H;
     dir = normalized(dir);
     float dist;
@@ -282,7 +282,7 @@ static bool generate_sample_legacy(const LegacyCtx& c, const Material& m, const 
         float cosTheta = std::sqrt(u1);
         float sinTheta = std::sqrt(1.0f - cosTheta * cosTheta);
         float phi = 2.0f * PI_F * u2;
-        dir = U * (sinTheta * std::cos(phi)) + Vb * (sinTheta * std::sin(phi)) + N * cosTheta;
+        dir = U * (sinTheta * rtx_cosf(phi)) + Vb * (sinTheta * rtx_sinf(phi)) + N * cosTheta;
         si.mult = sc.eval_tc(m.d.diffuse, m.d.diffuse_tex, s.uvw);
         si.prob = cosTheta / PI_F;
         si.lobe = LOBE_DIFFUSE;
@@ -307,7 +307,7 @@ static bool generate_sample_legacy(const LegacyCtx& c, const Material& m, const 
         float cosTheta = std::sqrt(u1);
         float sinTheta = std::sqrt(1.0f - cosTheta * cosTheta);
         float phi = 2.0f * PI_F * u2;
-        dir = U * (sinTheta * std::cos(phi)) + Vb * (sinTheta * std::sin(phi)) + N * cosTheta;
+        dir = U * (sinTheta * rtx_cosf(phi)) + Vb * (sinTheta * rtx_sinf(phi)) + N * cosTheta;
         si.mult = diff;
         si.prob = diffWeight / total;
         si.lobe = LOBE_DIFFUSE;
@@ -316,10 +316,10 @@ static bool generate_sample_legacy(const LegacyCtx& c, const Material& m, const 
         R = normalized(R);
         V3 U, Vb;
         build_onb(R, U, Vb);
-        float cosTheta = std::pow(u1, 1.0f / (alpha + 1.0f));
+        float cosTheta = rtx_powf(u1, 1.0f / (alpha + 1.0f));
         float sinTheta = std::sqrt(std::max(0.0f, 1.0f - cosTheta * cosTheta));
         float phi = 2.0f * PI_F * u2;
-        V3 H = U * (sinTheta * std::cos(phi)) + Vb * (sinTheta * std::sin(phi)) + R * cosTheta;
+        V3 H = U * (sinTheta * rtx_cosf(phi)) + Vb * (sinTheta * rtx_sinf(phi)) + R * cosTheta;
         H = normalized(H);
         if (phong) dir = H;                                   // :836-837
         else dir = normalized(2.0f * dot(V, H) * H - V);      // :744-748
@@ -340,10 +340,10 @@ static bool generate_sample_legacy(const LegacyCtx& c, const Material& m, const 
         if (alpha > 0.0f) {
             V3 U, Vb;
             build_onb(T, U, Vb);
-            float cosTheta = std::pow(u1, 1.0f / (alpha + 1.0f));
+            float cosTheta = rtx_powf(u1, 1.0f / (alpha + 1.0f));
             float sinTheta = std::sqrt(std::max(0.0f, 1.0f - cosTheta * cosTheta));
             float phi = 2.0f * PI_F * u2;
-            dir = U * (sinTheta * std::cos(phi)) + Vb * (sinTheta * std::sin(phi)) + T * cosTheta;
+            dir = U * (sinTheta * rtx_cosf(phi)) + Vb * (sinTheta * rtx_sinf(phi)) + T * cosTheta;
             dir = normalized(dir);
         }
         si.mult = refr;
@@ -415,12 +415,12 @@ static V3 shade(const LegacyCtx& c, const Material& m, const LegacyInfo& li) {
             local = local + (kd / PI_F) * Li * NdotL;
             const V3 H = normalized(Ldir + V);
             const float NdotH = std::max(0.0f, dot(N, H));
-            if (NdotH > 0.0f) local = local + (ks * (alpha + 2.0f) / (8.0f * PI_F)) * Li * std::pow(NdotH, alpha);
+            if (NdotH > 0.0f) local = local + (ks * (alpha + 2.0f) / (8.0f * PI_F)) * Li * rtx_powf(NdotH, alpha);
         } else {
             V3 lightContrib = (kd / PI_F) * Li * NdotL;
             const V3 R = normalized(2.0f * dot(N, Ldir) * N - Ldir);
             const float RdotV = std::max(0.0f, dot(R, V));
-            if (RdotV > 0.0f) lightContrib = lightContrib + (ks * (alpha + 1.0f) / (2.0f * PI_F)) * Li * std::pow(RdotV, alpha);
+            if (RdotV > 0.0f) lightContrib = lightContrib + (ks * (alpha + 1.0f) / (2.0f * PI_F)) * Li * rtx_powf(RdotV, alpha);
             local = local + lightContrib;
         }
     }

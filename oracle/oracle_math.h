@@ -6,6 +6,9 @@
 // (cyVector/cyColor are absent from the reference repository). Every operation is a plain
 // fp32 expression evaluated left to right; the file is compiled with -ffp-contract=off so no FMA is formed.
 #pragma once
+// powf / expf / sinf / cosf / tanf / asinf / acosf / atan2f: the routines the kernels evaluate too (stand-in for the
+// platform libm the reference calls; see the header). Shared on purpose: identical source, identical results.
+#include "../raytracer_amd/csrc/rtx_math.h"
 #include <cmath>
 #include <cstdint>
 #include <algorithm>

@@ -214,10 +214,10 @@ bool Mesh::intersect_sphere(const Ray& ray, Hit& hInfo, int hitSide) const {
     hInfo.front = front;
     const V3 n = normalized(hp);
     const float PIf = 3.14159265358979323846f;
-    const float phi = std::atan2(n.y, n.x);
-    const float theta = std::acos(std::min(1.0f, std::max(-1.0f, n.z)));
+    const float phi = rtx_atan2f(n.y, n.x);
+    const float theta = rtx_acosf(std::min(1.0f, std::max(-1.0f, n.z)));
     hInfo.uvw = V3((phi + PIf) / (2.0f * PIf), 1.0f - (theta / PIf), 0.0f);
-    const float sinTheta = std::sin(theta), cosTheta = std::cos(theta), sinPhi = std::sin(phi), cosPhi = std::cos(phi);
+    const float sinTheta = rtx_sinf(theta), cosTheta = rtx_cosf(theta), sinPhi = rtx_sinf(phi), cosPhi = rtx_cosf(phi);
     hInfo.dpdu = V3(-sinTheta * sinPhi * 2.0f * PIf, sinTheta * cosPhi * 2.0f * PIf, 0.0f);
     hInfo.dpdv = V3(-PIf * cosTheta * cosPhi, -PIf * cosTheta * sinPhi, PIf * sinTheta);
     hInfo.face = 0;
@@ -415,8 +415,8 @@ V3 TexMap::eval_raw(V3 uvw) const {
 // lat-long lookup with +z as the pole: u = atan2(y,x)/(2pi)+0.5, v = acos(z)/pi.
 V3 TexMap::eval_env(V3 dir) const {
     V3 d = safe_normalize(xf_vec(xf, dir));
-    float u = std::atan2(d.y, d.x) * (0.5f / PI_F) + 0.5f;
-    float v = std::acos(std::min(1.0f, std::max(-1.0f, d.z))) * (1.0f / PI_F);
+    float u = rtx_atan2f(d.y, d.x) * (0.5f / PI_F) + 0.5f;
+    float v = rtx_acosf(std::min(1.0f, std::max(-1.0f, d.z))) * (1.0f / PI_F);
     return eval_raw(V3(u, v, 0.0f));
 }
 

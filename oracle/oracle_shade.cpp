@@ -52,7 +52,7 @@ void pixel_shifts(int x, int y, float& shiftX, float& shiftY) {
 Ray generate_ray(const Camera& cam, float samplePosX, float samplePosY, int sampleIndex) {
     const int W = cam.W, H = cam.H;
     const float fovRad = cam.fov * 3.14159265f / 180.0f;
-    const float halfY = std::tan(0.5f * fovRad);
+    const float halfY = rtx_tanf(0.5f * fovRad);
     const float aspect = (H > 0) ? float(W) / float(H) : 1.0f;
     const float halfX = halfY * aspect;
     const V3 f = cam.dir;
@@ -73,8 +73,8 @@ Ray generate_ray(const Camera& cam, float samplePosX, float samplePosY, int samp
         float hy = halton(sampleIndex, 7);
         float rd = std::sqrt(hx);
         float theta = 2.0f * PI_F * hy;
-        float dx = rd * std::cos(theta);
-        float dy = rd * std::sin(theta);
+        float dx = rd * rtx_cosf(theta);
+        float dy = rd * rtx_sinf(theta);
         V3 lensPoint = cam.pos + r * (dx * aperture) + u * (dy * aperture);
         ray.p = lensPoint;
         ray.dir = normalized(pixelWorld - lensPoint);
@@ -88,7 +88,7 @@ Ray generate_ray(const Camera& cam, float samplePosX, float samplePosY, int samp
 // CameraAdapter.h:7-27
 Ray generate_camera_ray(const Camera& cam, int x, int y) {
     float fovRad = cam.fov * 3.14159265f / 180.0f;
-    float halfY = std::tan(0.5f * fovRad);
+    float halfY = rtx_tanf(0.5f * fovRad);
     float aspect = (cam.H > 0) ? float(cam.W) / float(cam.H) : 1.0f;
     float halfX = halfY * aspect;
     float ndcX = ((x + 0.5f) / float(cam.W)) * 2.0f - 1.0f;
@@ -121,7 +121,7 @@ float filter1d(int type, float radiusOverride, float x) {
             float sigma = radius * 0.5f;
             if (sigma <= 0.0f) sigma = 0.5f;
             float t = x / sigma;
-            return std::exp(-0.5f * t * t);
+            return rtx_expf(-0.5f * t * t);
         }
         case RTX_FILTER_MITCHELL: {
             const float B = 1.0f / 3.0f;
@@ -139,7 +139,7 @@ float filter1d(int type, float radiusOverride, float x) {
             if (x >= a) return 0.0f;
             if (x < 1e-6f) return 1.0f;
             float pix = PI_F * x;
-            return (a * std::sin(pix) * std::sin(pix / a)) / (pix * pix);
+            return (a * rtx_sinf(pix) * rtx_sinf(pix / a)) / (pix * pix);
         }
         default: {
             x = std::fabs(x);
@@ -154,7 +154,7 @@ void to_color24(V3 c, bool srgb, unsigned char out[3]) {
     float v[3] = {c.x, c.y, c.z};
     for (int i = 0; i < 3; ++i) {
         float x = v[i];
-        if (srgb) x = x < 0.0031308f ? x * 12.92f : std::pow(x, 0.41666f) * 1.055f - 0.055f;
+        if (srgb) x = x < 0.0031308f ? x * 12.92f : rtx_powf(x, 0.41666f) * 1.055f - 0.055f;
         x = std::max(x, 0.0f);
         x = std::min(x, 1.0f);
         out[i] = (unsigned char)(x * 255.0f);
@@ -186,7 +186,7 @@ bool light_generate_sample(const Light& L, const SInfo& sInfo, int lightIdx, V3&
     float z = 1.0f - 2.0f * u1;
     float rxy = std::sqrt(std::max(0.0f, 1.0f - z * z));
     float phi = 2.0f * PI_F * u2;
-    V3 onS = V3(rxy * std::cos(phi), rxy * std::sin(phi), z);
+    V3 onS = V3(rxy * rtx_cosf(phi), rxy * rtx_sinf(phi), z);
     V3 Lpos = L.position + L.size * onS;
     V3 wi = Lpos - P;
     float dist = len(wi);
@@ -253,14 +253,14 @@ void light_random_photon(const Light& L, const float u[4], Ray& r, V3& c) {
         float z = 1.0f - 2.0f * u1;
         float rxy = std::sqrt(std::max(0.0f, 1.0f - z * z));
         float phi = 2.0f * PI_F * u2;
-        pos = L.position + L.size * V3(rxy * std::cos(phi), rxy * std::sin(phi), z);
+        pos = L.position + L.size * V3(rxy * rtx_cosf(phi), rxy * rtx_sinf(phi), z);
     }
     float u1 = u[k++];
     float u2 = u[k++];
     float z = 1.0f - 2.0f * u1;
     float rxy = std::sqrt(std::max(0.0f, 1.0f - z * z));
     float phi = 2.0f * PI_F * u2;
-    V3 dir(rxy * std::cos(phi), rxy * std::sin(phi), z);
+    V3 dir(rxy * rtx_cosf(phi), rxy * rtx_sinf(phi), z);
     if (L.size > 0.0f) {
         V3 n = safe_normalize(pos - L.position);
         if (dot(dir, n) < 0.0f) dir = -dir;
@@ -359,8 +359,8 @@ static bool sample_phong_blinn(const PhongCtx& ctx, bool phong, const SInfo& sIn
         float u2 = sInfo.rnd(DIM_U2);
         float rxy = std::sqrt(u1);
         float phi = 2.0f * PI_F * u2;
-        float x = rxy * std::cos(phi);
-        float y = rxy * std::sin(phi);
+        float x = rxy * rtx_cosf(phi);
+        float y = rxy * rtx_sinf(phi);
         float z = std::sqrt(std::max(0.0f, 1.0f - u1));
         dir = safe_normalize(U * x + Vb * y + ctx.N * z);
         float cosN = std::max(0.0f, dot(ctx.N, dir));
@@ -384,15 +384,15 @@ static bool sample_phong_blinn(const PhongCtx& ctx, bool phong, const SInfo& sIn
             float u1 = sInfo.rnd(DIM_U1);
             float u2 = sInfo.rnd(DIM_U2);
             float phi = 2.0f * PI_F * u1;
-            float cosT = std::pow(u2, 1.0f / (a + 1.0f));
+            float cosT = rtx_powf(u2, 1.0f / (a + 1.0f));
             float sinT = std::sqrt(std::max(0.0f, 1.0f - cosT * cosT));
-            dir = safe_normalize(U * (std::cos(phi) * sinT) + Vb * (std::sin(phi) * sinT) + ctx.R * cosT);
+            dir = safe_normalize(U * (rtx_cosf(phi) * sinT) + Vb * (rtx_sinf(phi) * sinT) + ctx.R * cosT);
             float cosR = std::max(0.0f, dot(ctx.R, dir));
             float cosN = std::max(0.0f, dot(ctx.N, dir));
-            float pdfDir = ((a + 1.0f) / (2.0f * PI_F)) * std::pow(cosR, a);
-            if (specLobe) si.mult = color * ((a + 2.0f) / (2.0f * PI_F)) * std::pow(cosR, a) * cosN;  // :342
+            float pdfDir = ((a + 1.0f) / (2.0f * PI_F)) * rtx_powf(cosR, a);
+            if (specLobe) si.mult = color * ((a + 2.0f) / (2.0f * PI_F)) * rtx_powf(cosR, a) * cosN;  // :342
             else {
-                float brdf = ((a + 2.0f) / (2.0f * PI_F)) * std::pow(cosR, a);  // :398-399
+                float brdf = ((a + 2.0f) / (2.0f * PI_F)) * rtx_powf(cosR, a);  // :398-399
                 si.mult = color * brdf;
             }
             si.prob = (pl / total) * pdfDir;
@@ -405,9 +405,9 @@ static bool sample_phong_blinn(const PhongCtx& ctx, bool phong, const SInfo& sIn
             float u1 = sInfo.rnd(DIM_U1);
             float u2 = sInfo.rnd(DIM_U2);
             float phi = 2.0f * PI_F * u1;
-            float cosT = std::pow(u2, 1.0f / (a + 1.0f));
+            float cosT = rtx_powf(u2, 1.0f / (a + 1.0f));
             float sinT = std::sqrt(std::max(0.0f, 1.0f - cosT * cosT));
-            V3 h = safe_normalize(U * (std::cos(phi) * sinT) + Vb * (std::sin(phi) * sinT) + ctx.N * cosT);
+            V3 h = safe_normalize(U * (rtx_cosf(phi) * sinT) + Vb * (rtx_sinf(phi) * sinT) + ctx.N * cosT);
             float VoH;
             if (specLobe) {
                 dir = safe_normalize(reflect(-ctx.V, h));  // :358
@@ -419,10 +419,10 @@ static bool sample_phong_blinn(const PhongCtx& ctx, bool phong, const SInfo& sIn
             float NoL = std::max(0.0f, dot(ctx.N, dir));
             float NoH = std::max(0.0f, dot(ctx.N, h));
             if (NoL <= 0.0f || NoH <= 0.0f || VoH <= 1e-6f) return false;
-            float pdfH = ((a + 1.0f) / (2.0f * PI_F)) * std::pow(NoH, a);
+            float pdfH = ((a + 1.0f) / (2.0f * PI_F)) * rtx_powf(NoH, a);
             float pdfDir = pdfH / (4.0f * std::max(1e-6f, VoH));
             float invVoH = 1.0f / std::max(1e-6f, VoH);
-            V3 fSpec = color * ((a + 8.0f) / (8.0f * PI_F)) * std::pow(NoH, a) * invVoH;
+            V3 fSpec = color * ((a + 8.0f) / (8.0f * PI_F)) * rtx_powf(NoH, a) * invVoH;
             si.mult = fSpec;
             si.prob = (pl / total) * pdfDir;
             si.dist = 0.0f;
@@ -450,15 +450,15 @@ static bool sample_phong_blinn(const PhongCtx& ctx, bool phong, const SInfo& sIn
             float u1 = sInfo.rnd(DIM_U1);
             float u2 = sInfo.rnd(DIM_U2);
             float phi = 2.0f * PI_F * u1;
-            float cosTheta = std::pow(u2, 1.0f / (a + 1.0f));
+            float cosTheta = rtx_powf(u2, 1.0f / (a + 1.0f));
             float sinTheta = std::sqrt(std::max(0.0f, 1.0f - cosTheta * cosTheta));
-            dir = safe_normalize(U * (std::cos(phi) * sinTheta) + Vb * (std::sin(phi) * sinTheta) + T * cosTheta);
+            dir = safe_normalize(U * (rtx_cosf(phi) * sinTheta) + Vb * (rtx_sinf(phi) * sinTheta) + T * cosTheta);
             float cosT = std::max(0.0f, dot(T, dir));
             float absCosN = std::fabs(dot(ctx.N, dir));
             if (cosT <= 0.0f || absCosN <= 0.0f) return false;
-            float pdfDir = ((a + 1.0f) / (2.0f * PI_F)) * std::pow(cosT, a);
+            float pdfDir = ((a + 1.0f) / (2.0f * PI_F)) * rtx_powf(cosT, a);
             float etaScale = transmission_scale(eta);
-            V3 fTrans = transColor * ((a + 2.0f) / (2.0f * PI_F)) * std::pow(cosT, a);
+            V3 fTrans = transColor * ((a + 2.0f) / (2.0f * PI_F)) * rtx_powf(cosT, a);
             si.mult = fTrans * etaScale;
             si.prob = (pt / total) * pdfDir;
             si.dist = 0.0f;
@@ -470,9 +470,9 @@ static bool sample_phong_blinn(const PhongCtx& ctx, bool phong, const SInfo& sIn
             float u1 = sInfo.rnd(DIM_U1);
             float u2 = sInfo.rnd(DIM_U2);
             float phi = 2.0f * PI_F * u1;
-            float cosTheta = std::pow(u2, 1.0f / (a + 1.0f));
+            float cosTheta = rtx_powf(u2, 1.0f / (a + 1.0f));
             float sinTheta = std::sqrt(std::max(0.0f, 1.0f - cosTheta * cosTheta));
-            V3 h = safe_normalize(U * (std::cos(phi) * sinTheta) + Vb * (std::sin(phi) * sinTheta) + ctx.N * cosTheta);
+            V3 h = safe_normalize(U * (rtx_cosf(phi) * sinTheta) + Vb * (rtx_sinf(phi) * sinTheta) + ctx.N * cosTheta);
             if (dot(ctx.V, h) < 0.0f) h = -h;
             float cosI = -dot(h, I);
             float k = 1.0f - eta * eta * (1.0f - cosI * cosI);
@@ -492,13 +492,13 @@ static bool sample_phong_blinn(const PhongCtx& ctx, bool phong, const SInfo& sIn
             if (absCosN <= 0.0f || VoH <= 1e-6f || VoH * DoH >= 0.0f) return false;
             float denom = eta * VoH + DoH;
             if (std::fabs(denom) <= 1e-6f) return false;
-            float pdfH = ((a + 1.0f) / (2.0f * PI_F)) * std::pow(std::max(0.0f, dot(ctx.N, h)), a);
+            float pdfH = ((a + 1.0f) / (2.0f * PI_F)) * rtx_powf(std::max(0.0f, dot(ctx.N, h)), a);
             float dwh_dwi = std::fabs((eta * eta * DoH) / (denom * denom));
             float pdfDir = pdfH * dwh_dwi;
             if (pdfDir <= 0.0f) return false;
             float etaScale = transmission_scale(eta);
             float NoH = std::max(0.0f, dot(ctx.N, h));
-            V3 fTrans = transColor * ((a + 2.0f) / (2.0f * PI_F)) * std::pow(NoH, a);
+            V3 fTrans = transColor * ((a + 2.0f) / (2.0f * PI_F)) * rtx_powf(NoH, a);
             float factor = std::fabs(DoH * VoH) / std::max(1e-6f, std::fabs(dot(ctx.N, ctx.V)) * denom * denom);
             si.mult = fTrans * etaScale * factor;
             si.prob = (pt / total) * pdfDir;
@@ -542,20 +542,20 @@ static void evaluate_phong_blinn(const PhongCtx& ctx, bool phong, const SInfo& s
             if (phong) {
                 float cosR = std::max(0.0f, dot(ctx.R, dir));
                 if (cosR > 0.0f) {
-                    pdfRefl = ((a + 1.0f) / (2.0f * PI_F)) * std::pow(cosR, a);
+                    pdfRefl = ((a + 1.0f) / (2.0f * PI_F)) * rtx_powf(cosR, a);
                     pdfRefl *= pr / total;
-                    fRefl = reflColor * ((a + 2.0f) / (2.0f * PI_F)) * std::pow(cosR, a);
+                    fRefl = reflColor * ((a + 2.0f) / (2.0f * PI_F)) * rtx_powf(cosR, a);
                 }
             } else {
                 V3 H = safe_normalize(ctx.V + dir);
                 float NoH = std::max(0.0f, dot(ctx.N, H));
                 float VoH = std::max(0.0f, dot(ctx.V, H));
                 if (NoH > 0.0f && VoH > 1e-6f) {
-                    float pdfH = ((a + 1.0f) / (2.0f * PI_F)) * std::pow(NoH, a);
+                    float pdfH = ((a + 1.0f) / (2.0f * PI_F)) * rtx_powf(NoH, a);
                     float pdfDir = pdfH / (4.0f * std::max(1e-6f, VoH));
                     pdfRefl = pdfDir * (pr / total);
                     float invVoH = 1.0f / std::max(1e-6f, VoH);
-                    fRefl = reflColor * ((a + 8.0f) / (8.0f * PI_F)) * std::pow(NoH, a) * invVoH;
+                    fRefl = reflColor * ((a + 8.0f) / (8.0f * PI_F)) * rtx_powf(NoH, a) * invVoH;
                 }
             }
         }
@@ -572,19 +572,19 @@ static void evaluate_phong_blinn(const PhongCtx& ctx, bool phong, const SInfo& s
         if (phong) {
             float cosR = std::max(0.0f, dot(ctx.R, dir));
             if (ps > 0.0f && cosR > 0.0f) {
-                pdfSpec = ((a + 1.0f) / (2.0f * PI_F)) * std::pow(cosR, a);
+                pdfSpec = ((a + 1.0f) / (2.0f * PI_F)) * rtx_powf(cosR, a);
                 pdfSpec *= ps / total;
                 hasSpec = true;
-                fSpec = specColor * ((a + 2.0f) / (2.0f * PI_F)) * std::pow(cosR, a);
+                fSpec = specColor * ((a + 2.0f) / (2.0f * PI_F)) * rtx_powf(cosR, a);
             }
         } else {
             if (ps > 0.0f && blinnNoH > 0.0f && blinnVoH > 1e-6f) {
-                float pdfDir = ((a + 1.0f) / (2.0f * PI_F)) * std::pow(blinnNoH, a);
+                float pdfDir = ((a + 1.0f) / (2.0f * PI_F)) * rtx_powf(blinnNoH, a);
                 pdfDir /= (4.0f * std::max(1e-6f, blinnVoH));
                 pdfSpec = pdfDir * (ps / total);
                 hasSpec = true;
                 float invVoH = 1.0f / std::max(1e-6f, blinnVoH);
-                fSpec = specColor * ((a + 8.0f) / (8.0f * PI_F)) * std::pow(blinnNoH, a) * invVoH;
+                fSpec = specColor * ((a + 8.0f) / (8.0f * PI_F)) * rtx_powf(blinnNoH, a) * invVoH;
             }
         }
         if (!phong) mult = (fRefl + fDiff + fSpec) * cosN;
@@ -615,9 +615,9 @@ static void evaluate_phong_blinn(const PhongCtx& ctx, bool phong, const SInfo& s
                 V3 T = safe_normalize(eta * I + (eta * cosI - cosTIdeal) * ctx.N);
                 float cosT = std::max(0.0f, dot(T, dir));
                 if (cosT <= 0.0f) { si.set_void(); return; }
-                float pdfDir = ((a + 1.0f) / (2.0f * PI_F)) * std::pow(cosT, a);
+                float pdfDir = ((a + 1.0f) / (2.0f * PI_F)) * rtx_powf(cosT, a);
                 float etaScale = transmission_scale(eta);
-                V3 fTrans = transColor * ((a + 2.0f) / (2.0f * PI_F)) * std::pow(cosT, a);
+                V3 fTrans = transColor * ((a + 2.0f) / (2.0f * PI_F)) * rtx_powf(cosT, a);
                 mult = fTrans * etaScale;
                 pdf = (pt / total) * pdfDir;
                 si.lobe = LOBE_TRANSMISSION;
@@ -631,11 +631,11 @@ static void evaluate_phong_blinn(const PhongCtx& ctx, bool phong, const SInfo& s
                 if (VoH * WiH >= 0.0f) { si.set_void(); return; }
                 float denom = eta * VoH + WiH;
                 if (std::fabs(denom) <= 1e-6f) { si.set_void(); return; }
-                float pdfH = ((a + 1.0f) / (2.0f * PI_F)) * std::pow(NoH, a);
+                float pdfH = ((a + 1.0f) / (2.0f * PI_F)) * rtx_powf(NoH, a);
                 float dwh_dwi = std::fabs((eta * eta * WiH) / (denom * denom));
                 float pdfDir = pdfH * dwh_dwi;
                 float etaScale = transmission_scale(eta);
-                V3 fTrans = transColor * ((a + 2.0f) / (2.0f * PI_F)) * std::pow(NoH, a);
+                V3 fTrans = transColor * ((a + 2.0f) / (2.0f * PI_F)) * rtx_powf(NoH, a);
                 float factor = std::fabs(WiH * VoH) / std::max(1e-6f, absCosWo * denom * denom);
                 mult = fTrans * etaScale * factor;
                 pdf = (pt / total) * pdfDir;
@@ -659,7 +659,7 @@ static inline float ggx_g1(float alpha2, float NoX) {   // :747-751
     return (2.0f * NoX) / denom;
 }
 static inline V3 fresnel_schlick(V3 F0, float VoH) {   // :758-762
-    float k = std::pow(1.0f - VoH, 5.0f);
+    float k = rtx_powf(1.0f - VoH, 5.0f);
     return F0 + (V3(1.0f) - F0) * k;
 }
 struct MicroCtx {
@@ -700,8 +700,8 @@ static bool sample_microfacet(const MicroCtx& c, const SInfo& sInfo, V3& dir, Di
         build_onb(N, U, Vb);
         float rxy = std::sqrt(u1);
         float phi = 2.0f * PI_F * u2;
-        float x = rxy * std::cos(phi);
-        float y = rxy * std::sin(phi);
+        float x = rxy * rtx_cosf(phi);
+        float y = rxy * rtx_sinf(phi);
         float z = std::sqrt(std::max(0.0f, 1.0f - u1));
         dir = safe_normalize(U * x + Vb * y + N * z);
         float cosN = std::max(0.0f, dot(N, dir));
@@ -717,7 +717,7 @@ static bool sample_microfacet(const MicroCtx& c, const SInfo& sInfo, V3& dir, Di
         float phi = 2.0f * PI_F * u1;
         float cosT = std::sqrt((1.0f - u2) / (1.0f + (c.alpha * c.alpha - 1.0f) * u2));
         float sinT = std::sqrt(std::max(0.0f, 1.0f - cosT * cosT));
-        V3 h = safe_normalize(U * (std::cos(phi) * sinT) + Vb * (std::sin(phi) * sinT) + N * cosT);
+        V3 h = safe_normalize(U * (rtx_cosf(phi) * sinT) + Vb * (rtx_sinf(phi) * sinT) + N * cosT);
         dir = reflect(-V, h);
         if (dot(N, dir) <= 0.0f) return false;
         float NoV = std::max(0.0f, dot(N, V));
@@ -926,7 +926,7 @@ float visible(const Scene& scene, V3 origin, V3 normal, V3 dir, float maxDist, b
         cosTheta = std::min(std::max(cosTheta, 0.0f), 1.0f);
         float r0 = (etaI - etaT) / (etaI + etaT);
         r0 = r0 * r0;
-        float F = r0 + (1.0f - r0) * std::pow(1.0f - cosTheta, 5.0f);
+        float F = r0 + (1.0f - r0) * rtx_powf(1.0f - cosTheta, 5.0f);
         float transmit = std::max(0.0f, std::min(1.0f, (1.0f - F) * transFactor));
         visibility *= std::max(0.0f, std::min(1.0f, transmit));
         if (visibility <= 1e-4f) return 0.0f;
@@ -944,9 +944,9 @@ static inline V3 apply_absorption(V3 c, V3 absorption, float dist) {
     float absR = std::max(0.0f, absorption.x);
     float absG = std::max(0.0f, absorption.y);
     float absB = std::max(0.0f, absorption.z);
-    const float ar = std::exp(-absR * dist);
-    const float ag = std::exp(-absG * dist);
-    const float ab = std::exp(-absB * dist);
+    const float ar = rtx_expf(-absR * dist);
+    const float ag = rtx_expf(-absG * dist);
+    const float ab = rtx_expf(-absB * dist);
     return V3(std::min(c.x, c.x * ar), std::min(c.y, c.y * ag), std::min(c.z, c.z * ab));
 }
 
@@ -960,7 +960,7 @@ static inline void dir_to_screen_uv(const Camera& cam, V3 dir, float& u, float& 
     float sx = dot(dir, r) / dz;
     float sy = dot(dir, uvec) / dz;
     float fovRad = cam.fov * PI_F / 180.0f;
-    float halfY = std::tan(0.5f * fovRad);
+    float halfY = rtx_tanf(0.5f * fovRad);
     float aspect = (cam.H > 0) ? float(cam.W) / float(cam.H) : 1.0f;
     float halfX = halfY * aspect;
     float ndcX = sx / halfX;

@@ -119,8 +119,8 @@ __device__ __forceinline__ bool sample_phong_blinn(const PhongCtx& ctx, bool pho
         build_onb(ctx.N, U, Vb);
         const float rxy = sqrtf(u1);
         const float phi = 2.0f * PI_F * u2;
-        const float x = rxy * cosf(phi);
-        const float y = rxy * sinf(phi);
+        const float x = rxy * rtx_cosf(phi);
+        const float y = rxy * rtx_sinf(phi);
         const float z = sqrtf(fmaxf(0.0f, 1.0f - u1));
         dir = safe_normalize3(U * x + Vb * y + ctx.N * z);
         const float cosN = fmaxf(0.0f, dot3(ctx.N, dir));
@@ -139,25 +139,25 @@ __device__ __forceinline__ bool sample_phong_blinn(const PhongCtx& ctx, bool pho
             pl = pr;
         }
         const float phi = 2.0f * PI_F * u1;
-        const float cosT = powf(u2, 1.0f / (a + 1.0f));
+        const float cosT = rtx_powf(u2, 1.0f / (a + 1.0f));
         const float sinT = sqrtf(fmaxf(0.0f, 1.0f - cosT * cosT));
         if (phong) {
             f3 U, Vb;
             build_onb(ctx.R, U, Vb);
-            dir = safe_normalize3(U * (cosf(phi) * sinT) + Vb * (sinf(phi) * sinT) + ctx.R * cosT);
+            dir = safe_normalize3(U * (rtx_cosf(phi) * sinT) + Vb * (rtx_sinf(phi) * sinT) + ctx.R * cosT);
             const float cosR = fmaxf(0.0f, dot3(ctx.R, dir));
             const float cosN = fmaxf(0.0f, dot3(ctx.N, dir));
-            const float pdfDir = ((a + 1.0f) / (2.0f * PI_F)) * powf(cosR, a);
-            if (specLobe) si.mult = color * ((a + 2.0f) / (2.0f * PI_F)) * powf(cosR, a) * cosN;
+            const float pdfDir = ((a + 1.0f) / (2.0f * PI_F)) * rtx_powf(cosR, a);
+            if (specLobe) si.mult = color * ((a + 2.0f) / (2.0f * PI_F)) * rtx_powf(cosR, a) * cosN;
             else {
-                const float brdf = ((a + 2.0f) / (2.0f * PI_F)) * powf(cosR, a);
+                const float brdf = ((a + 2.0f) / (2.0f * PI_F)) * rtx_powf(cosR, a);
                 si.mult = color * brdf;
             }
             si.prob = (pl / total) * pdfDir;
         } else {
             f3 U, Vb;
             build_onb(ctx.N, U, Vb);
-            const f3 h = safe_normalize3(U * (cosf(phi) * sinT) + Vb * (sinf(phi) * sinT) + ctx.N * cosT);
+            const f3 h = safe_normalize3(U * (rtx_cosf(phi) * sinT) + Vb * (rtx_sinf(phi) * sinT) + ctx.N * cosT);
             float VoH;
             if (specLobe) {
                 dir = safe_normalize3(reflect3(-ctx.V, h));
@@ -169,10 +169,10 @@ __device__ __forceinline__ bool sample_phong_blinn(const PhongCtx& ctx, bool pho
             const float NoL = fmaxf(0.0f, dot3(ctx.N, dir));
             const float NoH = fmaxf(0.0f, dot3(ctx.N, h));
             if (NoL <= 0.0f || NoH <= 0.0f || VoH <= 1e-6f) return false;
-            const float pdfH = ((a + 1.0f) / (2.0f * PI_F)) * powf(NoH, a);
+            const float pdfH = ((a + 1.0f) / (2.0f * PI_F)) * rtx_powf(NoH, a);
             const float pdfDir = pdfH / (4.0f * fmaxf(1e-6f, VoH));
             const float invVoH = 1.0f / fmaxf(1e-6f, VoH);
-            si.mult = color * ((a + 8.0f) / (8.0f * PI_F)) * powf(NoH, a) * invVoH;
+            si.mult = color * ((a + 8.0f) / (8.0f * PI_F)) * rtx_powf(NoH, a) * invVoH;
             si.prob = (pl / total) * pdfDir;
         }
         si.dist = 0.0f;
@@ -182,7 +182,7 @@ __device__ __forceinline__ bool sample_phong_blinn(const PhongCtx& ctx, bool pho
         const float eta = s.front ? 1.0f / ctx.ior : ctx.ior;
         const f3 I = -ctx.V;
         const float phi = 2.0f * PI_F * u1;
-        const float cosTheta = powf(u2, 1.0f / (a + 1.0f));
+        const float cosTheta = rtx_powf(u2, 1.0f / (a + 1.0f));
         const float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
         if (phong) {
             const float cosI = -dot3(ctx.N, I);
@@ -199,19 +199,19 @@ __device__ __forceinline__ bool sample_phong_blinn(const PhongCtx& ctx, bool pho
             const f3 T = safe_normalize3(eta * I + (eta * cosI - cosTIdeal) * ctx.N);
             f3 U, Vb;
             build_onb(T, U, Vb);
-            dir = safe_normalize3(U * (cosf(phi) * sinTheta) + Vb * (sinf(phi) * sinTheta) + T * cosTheta);
+            dir = safe_normalize3(U * (rtx_cosf(phi) * sinTheta) + Vb * (rtx_sinf(phi) * sinTheta) + T * cosTheta);
             const float cosT = fmaxf(0.0f, dot3(T, dir));
             const float absCosN = fabsf(dot3(ctx.N, dir));
             if (cosT <= 0.0f || absCosN <= 0.0f) return false;
-            const float pdfDir = ((a + 1.0f) / (2.0f * PI_F)) * powf(cosT, a);
+            const float pdfDir = ((a + 1.0f) / (2.0f * PI_F)) * rtx_powf(cosT, a);
             const float etaScale = transmission_scale(eta);
-            const f3 fTrans = ctx.transColor * ((a + 2.0f) / (2.0f * PI_F)) * powf(cosT, a);
+            const f3 fTrans = ctx.transColor * ((a + 2.0f) / (2.0f * PI_F)) * rtx_powf(cosT, a);
             si.mult = fTrans * etaScale;
             si.prob = (pt / total) * pdfDir;
         } else {
             f3 U, Vb;
             build_onb(ctx.N, U, Vb);
-            f3 h = safe_normalize3(U * (cosf(phi) * sinTheta) + Vb * (sinf(phi) * sinTheta) + ctx.N * cosTheta);
+            f3 h = safe_normalize3(U * (rtx_cosf(phi) * sinTheta) + Vb * (rtx_sinf(phi) * sinTheta) + ctx.N * cosTheta);
             if (dot3(ctx.V, h) < 0.0f) h = -h;
             const float cosI = -dot3(h, I);
             const float k = 1.0f - eta * eta * (1.0f - cosI * cosI);
@@ -231,13 +231,13 @@ __device__ __forceinline__ bool sample_phong_blinn(const PhongCtx& ctx, bool pho
             if (absCosN <= 0.0f || VoH <= 1e-6f || VoH * DoH >= 0.0f) return false;
             const float denom = eta * VoH + DoH;
             if (fabsf(denom) <= 1e-6f) return false;
-            const float pdfH = ((a + 1.0f) / (2.0f * PI_F)) * powf(fmaxf(0.0f, dot3(ctx.N, h)), a);
+            const float pdfH = ((a + 1.0f) / (2.0f * PI_F)) * rtx_powf(fmaxf(0.0f, dot3(ctx.N, h)), a);
             const float dwh_dwi = fabsf((eta * eta * DoH) / (denom * denom));
             const float pdfDir = pdfH * dwh_dwi;
             if (pdfDir <= 0.0f) return false;
             const float etaScale = transmission_scale(eta);
             const float NoH = fmaxf(0.0f, dot3(ctx.N, h));
-            const f3 fTrans = ctx.transColor * ((a + 2.0f) / (2.0f * PI_F)) * powf(NoH, a);
+            const f3 fTrans = ctx.transColor * ((a + 2.0f) / (2.0f * PI_F)) * rtx_powf(NoH, a);
             const float factor = fabsf(DoH * VoH) / fmaxf(1e-6f, fabsf(dot3(ctx.N, ctx.V)) * denom * denom);
             si.mult = fTrans * etaScale * factor;
             si.prob = (pt / total) * pdfDir;
@@ -276,15 +276,15 @@ __device__ __forceinline__ void evaluate_phong_blinn(const PhongCtx& ctx, bool p
             const float cosR = fmaxf(0.0f, dot3(ctx.R, dir));
             if (pr > 0.0f && cosR > 0.0f) {
                 const f3 reflColor = clamp_max3(ctx.kr + ctx.fresnelRef, 1.0f);
-                pdfRefl = ((a + 1.0f) / (2.0f * PI_F)) * powf(cosR, a);
+                pdfRefl = ((a + 1.0f) / (2.0f * PI_F)) * rtx_powf(cosR, a);
                 pdfRefl *= pr / total;
-                fRefl = reflColor * ((a + 2.0f) / (2.0f * PI_F)) * powf(cosR, a);
+                fRefl = reflColor * ((a + 2.0f) / (2.0f * PI_F)) * rtx_powf(cosR, a);
             }
             if (ps > 0.0f && cosR > 0.0f) {
-                pdfSpec = ((a + 1.0f) / (2.0f * PI_F)) * powf(cosR, a);
+                pdfSpec = ((a + 1.0f) / (2.0f * PI_F)) * rtx_powf(cosR, a);
                 pdfSpec *= ps / total;
                 hasSpec = true;
-                fSpec = ctx.specColor * ((a + 2.0f) / (2.0f * PI_F)) * powf(cosR, a);
+                fSpec = ctx.specColor * ((a + 2.0f) / (2.0f * PI_F)) * rtx_powf(cosR, a);
             }
             mult = fRefl + (fDiff + fSpec) * cosN;
         } else {
@@ -292,7 +292,7 @@ __device__ __forceinline__ void evaluate_phong_blinn(const PhongCtx& ctx, bool p
             const float NoH = fmaxf(0.0f, dot3(ctx.N, H));
             const float VoH = fmaxf(0.0f, dot3(ctx.V, H));
             if (NoH > 0.0f && VoH > 1e-6f) {
-                const float powNoH = powf(NoH, a);
+                const float powNoH = rtx_powf(NoH, a);
                 if (pr > 0.0f) {
                     const f3 reflColor = clamp_max3(ctx.kr + ctx.fresnelRef, 1.0f);
                     const float pdfH = ((a + 1.0f) / (2.0f * PI_F)) * powNoH;
@@ -335,9 +335,9 @@ __device__ __forceinline__ void evaluate_phong_blinn(const PhongCtx& ctx, bool p
                 const f3 T = safe_normalize3(eta * I + (eta * cosI - cosTIdeal) * ctx.N);
                 const float cosT = fmaxf(0.0f, dot3(T, dir));
                 if (cosT <= 0.0f) return;
-                const float pdfDir = ((a + 1.0f) / (2.0f * PI_F)) * powf(cosT, a);
+                const float pdfDir = ((a + 1.0f) / (2.0f * PI_F)) * rtx_powf(cosT, a);
                 const float etaScale = transmission_scale(eta);
-                const f3 fTrans = ctx.transColor * ((a + 2.0f) / (2.0f * PI_F)) * powf(cosT, a);
+                const f3 fTrans = ctx.transColor * ((a + 2.0f) / (2.0f * PI_F)) * rtx_powf(cosT, a);
                 mult = fTrans * etaScale;
                 pdf = (pt / total) * pdfDir;
                 lobe = LOBE_TRANSMISSION;
@@ -351,11 +351,11 @@ __device__ __forceinline__ void evaluate_phong_blinn(const PhongCtx& ctx, bool p
                 if (VoH * WiH >= 0.0f) return;
                 const float denom = eta * VoH + WiH;
                 if (fabsf(denom) <= 1e-6f) return;
-                const float pdfH = ((a + 1.0f) / (2.0f * PI_F)) * powf(NoH, a);
+                const float pdfH = ((a + 1.0f) / (2.0f * PI_F)) * rtx_powf(NoH, a);
                 const float dwh_dwi = fabsf((eta * eta * WiH) / (denom * denom));
                 const float pdfDir = pdfH * dwh_dwi;
                 const float etaScale = transmission_scale(eta);
-                const f3 fTrans = ctx.transColor * ((a + 2.0f) / (2.0f * PI_F)) * powf(NoH, a);
+                const f3 fTrans = ctx.transColor * ((a + 2.0f) / (2.0f * PI_F)) * rtx_powf(NoH, a);
                 const float factor = fabsf(WiH * VoH) / fmaxf(1e-6f, absCosWo * denom * denom);
                 mult = fTrans * etaScale * factor;
                 pdf = (pt / total) * pdfDir;
@@ -384,7 +384,7 @@ __device__ __forceinline__ float ggx_g1(float alpha2, float NoX) {   // :747-751
     return (2.0f * NoX) / denom;
 }
 __device__ __forceinline__ f3 fresnel_schlick(f3 F0, float VoH) {   // :758-762
-    const float k = powf(1.0f - VoH, 5.0f);
+    const float k = rtx_powf(1.0f - VoH, 5.0f);
     return F0 + (mk3(1.0f) - F0) * k;
 }
 // common prologue of GenerateSample / GetSampleInfo (:768-785, :861-879), built once per hit; material slots as
@@ -422,8 +422,8 @@ __device__ __forceinline__ bool sample_microfacet(const MicroCtx& c, const SampC
         build_onb(N, U, Vb);
         const float rxy = sqrtf(u1);
         const float phi = 2.0f * PI_F * u2;
-        const float x = rxy * cosf(phi);
-        const float y = rxy * sinf(phi);
+        const float x = rxy * rtx_cosf(phi);
+        const float y = rxy * rtx_sinf(phi);
         const float z = sqrtf(fmaxf(0.0f, 1.0f - u1));
         dir = safe_normalize3(U * x + Vb * y + N * z);
         const float cosN = fmaxf(0.0f, dot3(N, dir));
@@ -439,7 +439,7 @@ __device__ __forceinline__ bool sample_microfacet(const MicroCtx& c, const SampC
         const float phi = 2.0f * PI_F * u1;
         const float cosT = sqrtf((1.0f - u2) / (1.0f + (c.alpha * c.alpha - 1.0f) * u2));
         const float sinT = sqrtf(fmaxf(0.0f, 1.0f - cosT * cosT));
-        const f3 h = safe_normalize3(U * (cosf(phi) * sinT) + Vb * (sinf(phi) * sinT) + N * cosT);
+        const f3 h = safe_normalize3(U * (rtx_cosf(phi) * sinT) + Vb * (rtx_sinf(phi) * sinT) + N * cosT);
         dir = reflect3(-V, h);
         if (dot3(N, dir) <= 0.0f) return false;
         const float NoV = fmaxf(0.0f, dot3(N, V));
@@ -546,7 +546,7 @@ __device__ __forceinline__ bool light_generate_sample(const DevLight& L, f3 P, f
     const float z = 1.0f - 2.0f * u1;
     const float rxy = sqrtf(fmaxf(0.0f, 1.0f - z * z));
     const float phi = 2.0f * PI_F * u2;
-    const f3 onS = mk3(rxy * cosf(phi), rxy * sinf(phi), z);
+    const f3 onS = mk3(rxy * rtx_cosf(phi), rxy * rtx_sinf(phi), z);
     const f3 Lpos = position + L.size * onS;
     const f3 wi = Lpos - P;
     const float dist = len3(wi);
@@ -632,14 +632,14 @@ __device__ __forceinline__ void light_random_photon(const DevLight& L, const flo
         const float z = 1.0f - 2.0f * u1;
         const float rxy = sqrtf(fmaxf(0.0f, 1.0f - z * z));
         const float phi = 2.0f * PI_F * u2;
-        pos = position + L.size * mk3(rxy * cosf(phi), rxy * sinf(phi), z);
+        pos = position + L.size * mk3(rxy * rtx_cosf(phi), rxy * rtx_sinf(phi), z);
     }
     const float u1 = u[k++];
     const float u2 = u[k++];
     const float z = 1.0f - 2.0f * u1;
     const float rxy = sqrtf(fmaxf(0.0f, 1.0f - z * z));
     const float phi = 2.0f * PI_F * u2;
-    f3 dir = mk3(rxy * cosf(phi), rxy * sinf(phi), z);
+    f3 dir = mk3(rxy * rtx_cosf(phi), rxy * rtx_sinf(phi), z);
     if (L.size > 0.0f) {
         const f3 n = safe_normalize3(pos - position);
         if (dot3(dir, n) < 0.0f) dir = -dir;

@@ -59,6 +59,12 @@ uint32_t launch_raygen(const DevCamera& cam, const PathPool& pool, const int* pi
 uint32_t launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm, const SegQ& qIn,
                       const uint32_t* queueIn, uint32_t n, int bounce, int maxBounces, unsigned long long seed, int sBase, int S,
                       const int* pixels, const SegQ& qOut, uint32_t* queueOut, const SegQ& qShadow, int hasMicrofacet,
+                      hipStream_t stream, uint32_t* keysOut = nullptr);
+// ray regrouping (kernels_sort.hip): path slots of queue (qIn, items) in the order of the keys shade wrote -> pool.sortItems
+size_t sort_temp_bytes(uint32_t n);
+int launch_sort_shade_queue(const DevScene& sc, const PathPool& pool, const SegQ& qIn, const uint32_t* items, uint32_t n, void* temp,
+                            size_t tempBytes, hipStream_t stream);
+int launch_sort_queue(const PathPool& pool, const SegQ& qIn, const uint32_t* items, uint32_t n, void* temp, size_t tempBytes,
                       hipStream_t stream);
 // the rest of a pass for its last n paths in one kernel (n <= RTX_TAIL_MAX_PATHS)
 #define RTX_TAIL_MAX_PATHS 65536u
@@ -84,3 +90,5 @@ void launch_stats_clear(const PathPool& pool, uint32_t n, hipStream_t stream);
 void launch_film_resolve(const rtx_film& film, uint32_t n, int srgb, float* linear, unsigned char* rgb8, hipStream_t stream);
 // dst += srcs[0 .. nSrc) (accum, count, guides by sum; z by min); all buffers on the device of `stream`; nSrc < RTX_GROUP_MAX
 void launch_film_merge(const rtx_film& dst, const rtx_film* srcs, int nSrc, uint32_t n, hipStream_t stream);
+// rtx_math.h routine `fn` on device arrays (rtx_debug_math)
+void launch_math_probe(int fn, const float* x, const float* y, uint32_t n, float* out, hipStream_t stream);

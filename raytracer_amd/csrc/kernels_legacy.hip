@@ -59,7 +59,7 @@ __device__ __forceinline__ f3 clamp01_3(f3 c) { return mk3(clamp01f(c.x), clamp0
 __device__ __forceinline__ f3 lg_absorption_factor(f3 absorption, float dist) {
     if (dist <= 0.0f) return mk3(1.0f);
     if (absorption.x == 0.0f && absorption.y == 0.0f && absorption.z == 0.0f) return mk3(1.0f);
-    return mk3(expf(-absorption.x * dist), expf(-absorption.y * dist), expf(-absorption.z * dist));
+    return mk3(rtx_expf(-absorption.x * dist), rtx_expf(-absorption.y * dist), rtx_expf(-absorption.z * dist));
 }
 
 // PointLight::IntersectRay of the legacy build (Shading_Legacy.cpp:212-235): distance or -1
@@ -143,11 +143,11 @@ __device__ __forceinline__ f3 lg_illuminate(const G& g, const SampCtx& sx, int o
     h2 -= floorf(h2);
     float h3 = (1.0f / 3.0f) * 1.0f + jy;   // Halton(1, 3)
     h3 -= floorf(h3);
-    const float gamma = asinf(light.size / distC);
-    const float cosTheta = 1.0f - h2 * (1.0f - cosf(gamma));
+    const float gamma = rtx_asinf(light.size / distC);
+    const float cosTheta = 1.0f - h2 * (1.0f - rtx_cosf(gamma));
     const float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
     const float phi = 2.0f * PI_F * h3;
-    const f3 sampleDir = normalized3(U * cosf(phi) * sinTheta + V * sinf(phi) * sinTheta + L * cosTheta);
+    const f3 sampleDir = normalized3(U * rtx_cosf(phi) * sinTheta + V * rtx_sinf(phi) * sinTheta + L * cosTheta);
     const float vis = lg_trace_shadow(g, sx, obj, sampleDir * distC, 1.0f, S);
     const float avgVis = vis / 1.0f;
     return I * avgVis * atten;
@@ -222,11 +222,11 @@ __device__ __forceinline__ void lg_illuminate_deferred(const SampCtx& sx, int ob
     h2 -= floorf(h2);
     float h3 = (1.0f / 3.0f) * 1.0f + jy;   // Halton(1, 3)
     h3 -= floorf(h3);
-    const float gamma = asinf(light.size / distC);
-    const float cosTheta = 1.0f - h2 * (1.0f - cosf(gamma));
+    const float gamma = rtx_asinf(light.size / distC);
+    const float cosTheta = 1.0f - h2 * (1.0f - rtx_cosf(gamma));
     const float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
     const float phi = 2.0f * PI_F * h3;
-    const f3 sampleDir = normalized3(U * cosf(phi) * sinTheta + V * sinf(phi) * sinTheta + L * cosTheta);
+    const f3 sampleDir = normalized3(U * rtx_cosf(phi) * sinTheta + V * rtx_sinf(phi) * sinTheta + L * cosTheta);
     lg_push_shadow(sx, obj, sampleDir * distC, 1.0f, w, S);
 }
 
@@ -274,10 +274,10 @@ __device__ __forceinline__ f3 lg_glossy_dir(const SampCtx& sx, f3 axis, float al
     build_onb(axis, U, Vb);
     const uint32_t d0 = isReflection ? LG_DIM_REFL : LG_DIM_REFR;
     const float u1 = sx.rnd(d0), u2 = sx.rnd(d0 + 1);
-    const float cosTheta = powf(u1, 1.0f / (alpha + 1.0f));
+    const float cosTheta = rtx_powf(u1, 1.0f / (alpha + 1.0f));
     const float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
     const float phi = 2.0f * PI_F * u2;
-    const f3 H = normalized3(U * cosf(phi) * sinTheta + Vb * sinf(phi) * sinTheta + axis * cosTheta);
+    const f3 H = normalized3(U * rtx_cosf(phi) * sinTheta + Vb * rtx_sinf(phi) * sinTheta + axis * cosTheta);
     const f3 dir = isReflection ? (2.0f * dot3(V, H) * H - V) : H;
     return normalized3(dir);
 }
@@ -292,7 +292,7 @@ __device__ __forceinline__ bool lg_generate_sample(const DevScene& sc, const Dev
         const float cosTheta = sqrtf(u1);
         const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
         const float phi = 2.0f * PI_F * u2;
-        dir = U * (sinTheta * cosf(phi)) + Vb * (sinTheta * sinf(phi)) + N * cosTheta;
+        dir = U * (sinTheta * rtx_cosf(phi)) + Vb * (sinTheta * rtx_sinf(phi)) + N * cosTheta;
         si.mult = eval_tc(sc, m.kd, m.kd_tex, s.uvw);
         si.prob = cosTheta / PI_F;
         si.lobe = LOBE_DIFFUSE;
@@ -317,7 +317,7 @@ __device__ __forceinline__ bool lg_generate_sample(const DevScene& sc, const Dev
         const float cosTheta = sqrtf(u1);
         const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
         const float phi = 2.0f * PI_F * u2;
-        dir = U * (sinTheta * cosf(phi)) + Vb * (sinTheta * sinf(phi)) + N * cosTheta;
+        dir = U * (sinTheta * rtx_cosf(phi)) + Vb * (sinTheta * rtx_sinf(phi)) + N * cosTheta;
         si.mult = diff;
         si.prob = diffWeight / total;
         si.lobe = LOBE_DIFFUSE;
@@ -326,10 +326,10 @@ __device__ __forceinline__ bool lg_generate_sample(const DevScene& sc, const Dev
         R = normalized3(R);
         f3 U, Vb;
         build_onb(R, U, Vb);
-        const float cosTheta = powf(u1, 1.0f / (alpha + 1.0f));
+        const float cosTheta = rtx_powf(u1, 1.0f / (alpha + 1.0f));
         const float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
         const float phi = 2.0f * PI_F * u2;
-        f3 H = U * (sinTheta * cosf(phi)) + Vb * (sinTheta * sinf(phi)) + R * cosTheta;
+        f3 H = U * (sinTheta * rtx_cosf(phi)) + Vb * (sinTheta * rtx_sinf(phi)) + R * cosTheta;
         H = normalized3(H);
         if (phong) dir = H;
         else dir = normalized3(2.0f * dot3(V, H) * H - V);
@@ -353,10 +353,10 @@ __device__ __forceinline__ bool lg_generate_sample(const DevScene& sc, const Dev
         if (alpha > 0.0f) {
             f3 U, Vb;
             build_onb(T, U, Vb);
-            const float cosTheta = powf(u1, 1.0f / (alpha + 1.0f));
+            const float cosTheta = rtx_powf(u1, 1.0f / (alpha + 1.0f));
             const float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
             const float phi = 2.0f * PI_F * u2;
-            dir = U * (sinTheta * cosf(phi)) + Vb * (sinTheta * sinf(phi)) + T * cosTheta;
+            dir = U * (sinTheta * rtx_cosf(phi)) + Vb * (sinTheta * rtx_sinf(phi)) + T * cosTheta;
             dir = normalized3(dir);
         }
         si.mult = refr;
@@ -435,12 +435,12 @@ __device__ __forceinline__ void lg_shade(const G& g, const DevMaterial& m, const
             local = local + (kd / PI_F) * Li * NdotL;
             const f3 H = normalized3(Ldir + V);
             const float NdotH = fmaxf(0.0f, dot3(N, H));
-            if (NdotH > 0.0f) local = local + (ks * (alpha + 2.0f) / (8.0f * PI_F)) * Li * powf(NdotH, alpha);
+            if (NdotH > 0.0f) local = local + (ks * (alpha + 2.0f) / (8.0f * PI_F)) * Li * rtx_powf(NdotH, alpha);
         } else {
             f3 lightContrib = (kd / PI_F) * Li * NdotL;
             const f3 R = normalized3(2.0f * dot3(N, Ldir) * N - Ldir);
             const float RdotV = fmaxf(0.0f, dot3(R, V));
-            if (RdotV > 0.0f) lightContrib = lightContrib + (ks * (alpha + 1.0f) / (2.0f * PI_F)) * Li * powf(RdotV, alpha);
+            if (RdotV > 0.0f) lightContrib = lightContrib + (ks * (alpha + 1.0f) / (2.0f * PI_F)) * Li * rtx_powf(RdotV, alpha);
             local = local + lightContrib;
         }
     }
@@ -499,11 +499,11 @@ __device__ __forceinline__ void lg_shade(const G& g, const DevMaterial& m, const
             if (!phong) {
                 const f3 H = normalized3(Ldir + V);
                 const float NdotH = fmaxf(0.0f, dot3(N, H));
-                if (NdotH > 0.0f) per = per + (ks * (alpha + 2.0f) / (8.0f * PI_F)) * powf(NdotH, alpha);
+                if (NdotH > 0.0f) per = per + (ks * (alpha + 2.0f) / (8.0f * PI_F)) * rtx_powf(NdotH, alpha);
             } else {
                 const f3 R = normalized3(2.0f * dot3(N, Ldir) * N - Ldir);
                 const float RdotV = fmaxf(0.0f, dot3(R, V));
-                if (RdotV > 0.0f) per = per + (ks * (alpha + 1.0f) / (2.0f * PI_F)) * powf(RdotV, alpha);
+                if (RdotV > 0.0f) per = per + (ks * (alpha + 1.0f) / (2.0f * PI_F)) * rtx_powf(RdotV, alpha);
             }
             lg_illuminate_deferred(sx, obj, light, l, wLocal * per, S);
         }

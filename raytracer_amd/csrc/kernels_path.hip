@@ -90,8 +90,8 @@ __global__ void raygen_kernel(DevCamera cam, PathPool pool, const int* __restric
                 const float ly = halton<7>(sampleIndex);
                 const float rdisk = sqrtf(lx);
                 const float theta = 2.0f * PI_F * ly;
-                const float dx = rdisk * cosf(theta);
-                const float dy = rdisk * sinf(theta);
+                const float dx = rdisk * rtx_cosf(theta);
+                const float dy = rdisk * rtx_sinf(theta);
                 const f3 lensPoint = pos + r * (dx * cam.aperture) + u * (dy * cam.aperture);
                 ro = lensPoint;
                 rd = normalized3(pixelWorld - lensPoint);
@@ -116,6 +116,27 @@ __global__ void raygen_kernel(DevCamera cam, PathPool pool, const int* __restric
     if (valid) queueOut[q] = slot;
 }
 
+// 5 bits -> every third bit
+__device__ __forceinline__ uint32_t spread5(uint32_t v) {
+    v &= 31u;
+    v = (v | (v << 8)) & 0x100Fu;
+    v = (v | (v << 4)) & 0x10C3u;
+    v = (v | (v << 2)) & 0x1249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t ray_sort_key(const DevScene& sc, const float4 ra, const float4 rb) {
+    uint32_t c[3];
+    const float o[3] = {ra.x, ra.y, ra.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float ext = sc.bounds[a + 3] - sc.bounds[a];
+        const float f = ext > 0.0f ? (o[a] - sc.bounds[a]) / ext * 32.0f : 0.0f;
+        c[a] = (uint32_t)fminf(fmaxf(f, 0.0f), 31.0f);
+    }
+    const uint32_t oct = (rb.x < 0.0f ? 1u : 0u) | (rb.y < 0.0f ? 2u : 0u) | (rb.z < 0.0f ? 4u : 0u);
+    return (oct << 15) | spread5(c[0]) | (spread5(c[1]) << 1) | (spread5(c[2]) << 2);
+}
+
 // ---- shade (per-vertex body: shade_body.h) -----------------------------------------------------------------------
 #ifndef SHADE_WAVES_PER_EU
 #define SHADE_WAVES_PER_EU 3
@@ -125,7 +146,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
                                                     SegQ qIn, const uint32_t* __restrict__ queueIn, uint32_t n, int bounce,
                                                     int maxBounces, unsigned long long seed, int sBase, int S,
                                                     const int* __restrict__ pixels, SegQ qOut, uint32_t* __restrict__ queueOut,
-                                                    SegQ qShadow) {
+                                                    SegQ qShadow, uint32_t* __restrict__ keysOut) {
     __shared__ uint32_t qtab[SEGQ_TABLE_WORDS];
     segq_load_table(qIn, qtab);
     __syncthreads();
@@ -141,7 +162,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
     }
     // ---- surviving paths -> next queue ----
     const uint32_t q = segq_append(qOut, alive, 1u);
-    if (alive) queueOut[q] = slot;
+    if (alive) {
+        queueOut[q] = slot;
+        if (keysOut) {   // regrouping key of the path's next ray (kernels_sort.hip): origin cell in Morton order, direction octant
+            const float4 ra = pool.rays[2 * (size_t)slot], rb = pool.rays[2 * (size_t)slot + 1];
+            keysOut[q] = ray_sort_key(sc, ra, rb);
+        }
+    }
 }
 
 // ---- shadow --------------------------------------------------------------------------------------------------
@@ -266,7 +293,7 @@ __device__ __forceinline__ float filter1d(int type, float radius, float x) {   /
             float sigma = radius * 0.5f;
             if (sigma <= 0.0f) sigma = 0.5f;
             const float t = x / sigma;
-            return expf(-0.5f * t * t);
+            return rtx_expf(-0.5f * t * t);
         }
         case RTX_FILTER_MITCHELL: {
             const float B = 1.0f / 3.0f;
@@ -284,7 +311,7 @@ __device__ __forceinline__ float filter1d(int type, float radius, float x) {   /
             if (x >= a) return 0.0f;
             if (x < 1e-6f) return 1.0f;
             const float pix = PI_F * x;
-            return (a * sinf(pix) * sinf(pix / a)) / (pix * pix);
+            return (a * rtx_sinf(pix) * rtx_sinf(pix / a)) / (pix * pix);
         }
         default: {
             x = fabsf(x);
@@ -455,15 +482,15 @@ uint32_t launch_raygen(const DevCamera& cam, const PathPool& pool, const int* pi
 uint32_t launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm, const SegQ& qIn,
                       const uint32_t* queueIn, uint32_t n, int bounce, int maxBounces, unsigned long long seed, int sBase, int S,
                       const int* pixels, const SegQ& qOut, uint32_t* queueOut, const SegQ& qShadow, int hasMicrofacet,
-                      hipStream_t stream) {
+                      hipStream_t stream, uint32_t* keysOut) {
     if (!n) return 0;
     const uint32_t grid = (n + 255) / 256;
     if (hasMicrofacet)
         hipLaunchKernelGGL(shade_kernel<true>, dim3(grid), dim3(256), 0, stream, sc, cam, pool, pm, qIn, queueIn, n, bounce, maxBounces,
-                           seed, sBase, S, pixels, qOut, queueOut, qShadow);
+                           seed, sBase, S, pixels, qOut, queueOut, qShadow, keysOut);
     else
         hipLaunchKernelGGL(shade_kernel<false>, dim3(grid), dim3(256), 0, stream, sc, cam, pool, pm, qIn, queueIn, n, bounce, maxBounces,
-                           seed, sBase, S, pixels, qOut, queueOut, qShadow);
+                           seed, sBase, S, pixels, qOut, queueOut, qShadow, keysOut);
     return grid;
 }
 void launch_shadow(const DevScene& sc, const LaunchCfg& cfg, const PathPool& pool, const SegQ& q, uint32_t n, int useTransmittance) {

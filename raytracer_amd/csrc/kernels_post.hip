@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
+#include "rtx_math.h"
 #include "pathstate.h"
 #include "adaptive.h"
 
@@ -58,7 +59,7 @@ __global__ void film_resolve_kernel(rtx_film film, uint32_t n, int srgb, float* 
     for (int k = 0; k < 3; ++k) {
         if (linear) linear[3 * (size_t)i + k] = c[k];
         float x = c[k];
-        if (srgb) x = x < 0.0031308f ? x * 12.92f : powf(x, 0.41666f) * 1.055f - 0.055f;
+        if (srgb) x = x < 0.0031308f ? x * 12.92f : rtx_powf(x, 0.41666f) * 1.055f - 0.055f;
         x = fmaxf(x, 0.0f);
         x = fminf(x, 1.0f);
         if (rgb8) rgb8[3 * (size_t)i + k] = (unsigned char)(x * 255.0f);
@@ -105,7 +106,7 @@ __global__ void median3_kernel(const float* __restrict__ src, int W, int H, int 
         if (linear) linear[3 * i + c] = m;
         if (rgb8) {   // Denoiser.cpp:108-118: clamp, optional sRGB, truncate
             m = fminf(fmaxf(m, 0.0f), 1.0f);
-            if (srgb) m = m < 0.0031308f ? m * 12.92f : powf(m, 0.41666f) * 1.055f - 0.055f;
+            if (srgb) m = m < 0.0031308f ? m * 12.92f : rtx_powf(m, 0.41666f) * 1.055f - 0.055f;
             rgb8[3 * i + c] = (unsigned char)fminf(fmaxf(m * 255.0f, 0.0f), 255.0f);
         }
     }
@@ -167,4 +168,26 @@ void launch_adaptive(const PathPool& pool, const int* pixels, uint32_t nPix, flo
 }
 void launch_film_resolve(const rtx_film& film, uint32_t n, int srgb, float* linear, unsigned char* rgb8, hipStream_t stream) {
     hipLaunchKernelGGL(film_resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, film, n, srgb, linear, rgb8);
+}
+
+// rtx_debug_math: the shared elementary functions (rtx_math.h) evaluated on the device
+__global__ void math_probe_kernel(int fn, const float* __restrict__ x, const float* __restrict__ y, uint32_t n, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r;
+    switch (fn) {
+        case 0: r = rtx_powf(x[i], y[i]); break;
+        case 1: r = rtx_expf(x[i]); break;
+        case 2: r = rtx_sinf(x[i]); break;
+        case 3: r = rtx_cosf(x[i]); break;
+        case 4: r = rtx_tanf(x[i]); break;
+        case 5: r = rtx_asinf(x[i]); break;
+        case 6: r = rtx_acosf(x[i]); break;
+        default: r = rtx_atan2f(x[i], y[i]); break;
+    }
+    out[i] = r;
+}
+void launch_math_probe(int fn, const float* x, const float* y, uint32_t n, float* out, hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(math_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, fn, x, y, n, out);
 }

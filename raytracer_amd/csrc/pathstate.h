@@ -12,6 +12,7 @@
 #define PF_LAST_DELTA 1u
 #define PF_INSIDE_MEDIUM 2u
 #define PF_HAS_PREV 4u
+#define RTX_SORT_KEY_BITS 18   // 3 octant bits above 15 Morton bits of a 32^3 origin cell
 
 struct DevPhotonMap {
     const float4* pos;      // xyz, w unused          (sorted by cell)
@@ -47,6 +48,12 @@ struct PathPool {
     uint32_t* queueB;
     float4* shadowQ;        // 2 per entry: {offset origin xyz, maxDist}, {unit dir xyz, bits(slot*8+light)}
     SegQ qA, qB, qS;        // control words of queueA / queueB / shadowQ
+    // ray regrouping before extend (kernels_sort.hip; allocated only when it is switched on)
+    uint32_t* sortKeys;     // key of the ray of every queue entry, written by shade_kernel next to the entry (same index)
+    uint32_t* sortKeysIn;   // dense copies for the radix sort
+    uint32_t* sortKeysOut;
+    uint32_t* sortItemsIn;
+    uint32_t* sortItems;    // path slots in key order: the item list of the next extend launch
     uint32_t* totals;       // [0] entries of the queue shade appended to, [1] entries of the shadow queue
     uint32_t* counters;     // scratch counters ([8] adaptive refinement list)
     // per pixel (full frame)

@@ -1,5 +1,6 @@
 // C ABI (include/rtx.h): device management, scene upload and the ray-casting entry points.
 #include "rtx_internal.h"
+#include "rtx_math.h"
 #include <cmath>
 #include <cstring>
 
@@ -63,7 +64,7 @@ int make_dev_camera(const rtx_camera* cam, DevCamera& c) {
     if (!cam || cam->width <= 0 || cam->height <= 0) return rtx_fail(RTX_ERR_INVALID, "invalid camera");
     // RayCaster.cpp:717-724 (same constants as CameraAdapter.h:8-21), evaluated once per frame in fp32
     const float fovRad = cam->fov * 3.14159265f / 180.0f;
-    c.halfY = std::tan(0.5f * fovRad);
+    c.halfY = rtx_tanf(0.5f * fovRad);   // the routine the kernels and the oracle use (rtx_math.h)
     const float aspect = (cam->height > 0) ? float(cam->width) / float(cam->height) : 1.0f;
     c.halfX = c.halfY * aspect;
     const float* f = cam->dir;
@@ -304,6 +305,43 @@ int rtx_debug_queue_layout(uint32_t producer_blocks, uint32_t block_threads, uin
     for (uint32_t s = 0; s < QSEG; ++s) start[s] = segq_first_block(s, producer_blocks) * block_threads * mult;
     if (segment_of_block)
         for (uint32_t b = 0; b < producer_blocks; ++b) segment_of_block[b] = segq_segment_of_block(b, producer_blocks);
+    return RTX_OK;
+}
+
+int rtx_debug_math(int fn, const float* x, const float* y, size_t n, float* out, int on_device) {
+    if (fn < 0 || fn > 7 || (n && (!x || !y || !out))) return rtx_fail(RTX_ERR_INVALID, "bad argument");
+    if (n > 0x7FFFFFFFull) return rtx_fail(RTX_ERR_TOO_LARGE, "too many values");
+    if (!on_device) {   // the host side of this library (make_dev_camera evaluates rtx_tanf there)
+        for (size_t i = 0; i < n; ++i) {
+            switch (fn) {
+                case 0: out[i] = rtx_powf(x[i], y[i]); break;
+                case 1: out[i] = rtx_expf(x[i]); break;
+                case 2: out[i] = rtx_sinf(x[i]); break;
+                case 3: out[i] = rtx_cosf(x[i]); break;
+                case 4: out[i] = rtx_tanf(x[i]); break;
+                case 5: out[i] = rtx_asinf(x[i]); break;
+                case 6: out[i] = rtx_acosf(x[i]); break;
+                default: out[i] = rtx_atan2f(x[i], y[i]); break;
+            }
+        }
+        return RTX_OK;
+    }
+    if (rtx_device_count() <= 0) return rtx_fail(RTX_ERR_NO_DEVICE, "no HIP device present");
+    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    if (!n) return RTX_OK;
+    hipError_t e = hipMalloc((void**)&dx, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&dy, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&dout, n * 4);
+    if (e == hipSuccess) e = hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch_math_probe(fn, dx, dy, (uint32_t)n, dout, nullptr);
+        e = hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost);
+    }
+    if (dx) (void)hipFree(dx);
+    if (dy) (void)hipFree(dy);
+    if (dout) (void)hipFree(dout);
+    if (e != hipSuccess) return rtx_fail(RTX_ERR_HIP, std::string("math probe: ") + hipGetErrorString(e));
     return RTX_OK;
 }
 

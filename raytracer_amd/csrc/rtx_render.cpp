@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 struct PathPoolHost {
     PathPool dev{};
@@ -22,7 +23,10 @@ struct PathPoolHost {
     // second stream: the shadow kernel of bounce k runs beside the extend kernel of bounce k+1
     hipStream_t sideStream = nullptr;
     hipEvent_t sideDone = nullptr;
+    void* sortTemp = nullptr;     // in allocs
+    hipEvent_t evTotal0 = nullptr, evTotal1 = nullptr;   // whole-call timing; owned here so that no error path leaks them
     uint2* sideSpill = nullptr;   // its own traversal spill slab (both kernels are in flight at once)
+    size_t sortTempBytes = 0;
     void release() {
         if (sideStream) {
             (void)hipStreamSynchronize(sideStream);
@@ -33,6 +37,9 @@ struct PathPoolHost {
             (void)hipEventDestroy(sideDone);
             sideDone = nullptr;
         }
+        if (evTotal0) (void)hipEventDestroy(evTotal0);
+        if (evTotal1) (void)hipEventDestroy(evTotal1);
+        evTotal0 = evTotal1 = nullptr;
         sideSpill = nullptr;   // in allocs
         for (void* p : allocs) (void)hipFree(p);
         allocs.clear();
@@ -109,6 +116,17 @@ static int ensure_pool(rtx_scene* s, uint32_t slots, size_t framePixels, size_t 
     PA(statSum, ph->framePixels);
     PA(statSum2, ph->framePixels);
     PA(rayCounters, 8);
+    const char* eSort = std::getenv("RTX_AMD_SORT");
+    const char* eSortShade = std::getenv("RTX_AMD_SORT_SHADE");
+    if ((eSort && std::atoi(eSort) != 0) || (eSortShade && std::atoi(eSortShade) != 0)) {
+        PA(sortKeys, qcap);
+        PA(sortKeysIn, qcap);
+        PA(sortKeysOut, qcap);
+        PA(sortItemsIn, qcap);
+        PA(sortItems, qcap);
+        ph->sortTempBytes = sort_temp_bytes((uint32_t)qcap);
+        if ((rc = pool_alloc(ph, (char**)&ph->sortTemp, ph->sortTempBytes)) != RTX_OK) return rc;
+    }
 #undef PA
     return RTX_OK;
 }
@@ -286,9 +304,9 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
 
     rtx_stats out;
     std::memset(&out, 0, sizeof(out));
-    hipEvent_t evTotal0 = nullptr, evTotal1 = nullptr;
-    RTX_HIP(hipEventCreate(&evTotal0));
-    RTX_HIP(hipEventCreate(&evTotal1));
+    if (!ph->evTotal0) RTX_HIP(hipEventCreate(&ph->evTotal0));
+    if (!ph->evTotal1) RTX_HIP(hipEventCreate(&ph->evTotal1));
+    const hipEvent_t evTotal0 = ph->evTotal0, evTotal1 = ph->evTotal1;
     RTX_HIP(hipEventRecord(evTotal0, st));
 
     if (nPix) RTX_HIP(hipMemcpyAsync(pool.pixels, list.data(), (size_t)nPix * sizeof(int), hipMemcpyHostToDevice, st));
@@ -317,12 +335,23 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     if (overlap && !legacy && !ph->sideStream) {
         RTX_HIP(hipStreamCreateWithFlags(&ph->sideStream, hipStreamNonBlocking));
         RTX_HIP(hipEventCreateWithFlags(&ph->sideDone, hipEventDisableTiming));
-        if ((rc = pool_alloc(ph, &ph->sideSpill, (size_t)s->cfg.gridBlocks * TRAV_BLOCK * STACK_GLOBAL)) != RTX_OK) return rc;
+        if ((rc = pool_alloc(ph, &ph->sideSpill, (size_t)s->cfg.gridBlocks * TRAV_BLOCK * STACK_GLOBAL)) != RTX_OK) {
+            rtx_scene_release_pool(s);   // stream, event and every pool allocation; the next call starts from scratch
+            return rc;
+        }
     }
     LaunchCfg sideCfg = s->cfg;
     sideCfg.stream = ph->sideStream;
     sideCfg.spill = ph->sideSpill;
     bool sidePending = false;   // a shadow launch on the side stream that the main stream has not waited for yet
+    bool sortedNext = false;    // the next extend launch reads pool.sortItems (RTX_AMD_SORT)
+    uint32_t sortMin = 1u << 18;
+    const char* eSortRays = std::getenv("RTX_AMD_SORT");
+    const char* eSortShadeRun = std::getenv("RTX_AMD_SORT_SHADE");
+    if (const char* e = std::getenv("RTX_AMD_SORT_MIN")) sortMin = (uint32_t)std::atol(e);
+    const int sortKind = std::getenv("RTX_AMD_SORT_IN_EXTEND") ? 0 : 2;
+    const bool sortRays = pool.sortKeys && eSortRays && std::atoi(eSortRays) != 0;
+    const bool sortShade = pool.sortKeys && eSortShadeRun && std::atoi(eSortShadeRun) != 0;   // where the sort's time is booked (extend or shade)
 
     s->cancel.store(0);
     PassTimers tm{ph};
@@ -362,16 +391,30 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 else out.rays_bounce += n;
                 tm.nextItems = n;
                 tm.begin(0, st);
-                launch_extend_queue(s->dev, s->cfg, pool.rays, sqIn, qin, n, RTX_HIT_FRONT_AND_BACK, 1, pool.hits);
+                if (sortedNext) {   // the bounce rays in key order (kernels_sort.hip)
+                    launch_segq_identity(s->cfg.identQ, n, st);
+                    launch_extend_queue(s->dev, s->cfg, pool.rays, s->cfg.identQ, pool.sortItems, n, RTX_HIT_FRONT_AND_BACK, 1, pool.hits);
+                } else
+                    launch_extend_queue(s->dev, s->cfg, pool.rays, sqIn, qin, n, RTX_HIT_FRONT_AND_BACK, 1, pool.hits);
                 tm.end(st);
+                sortedNext = false;
                 out.extend_launches++;
                 if (sidePending) {
                     RTX_HIP(hipStreamWaitEvent(st, ph->sideDone, 0));
                     sidePending = false;
                 }
                 tm.begin(2, st);
-                const uint32_t gridShade = launch_shade(s->dev, dc, pool, pm, sqIn, qin, n, bounce, rp->max_bounces, rp->seed, sBase, Sp,
-                                                        curPixels, sqOut, qout, pool.qS, s->hasMicrofacet, st);
+                const uint32_t* shadeItems = qin;
+                SegQ shadeQ = sqIn;
+                if (sortShade && bounce >= 1 && n >= sortMin) {   // vertices regrouped by what they will run (kernels_sort.hip)
+                    if (launch_sort_shade_queue(s->dev, pool, sqIn, qin, n, ph->sortTemp, ph->sortTempBytes, st) != 0)
+                        return rtx_fail(RTX_ERR_HIP, "shade sort failed");
+                    launch_segq_identity(s->cfg.identQ, n, st);
+                    shadeItems = pool.sortItems;
+                    shadeQ = s->cfg.identQ;
+                }
+                const uint32_t gridShade = launch_shade(s->dev, dc, pool, pm, shadeQ, shadeItems, n, bounce, rp->max_bounces, rp->seed, sBase, Sp,
+                                                        curPixels, sqOut, qout, pool.qS, s->hasMicrofacet, st, sortRays ? pool.sortKeys : nullptr);
                 tm.end(st);
                 launch_segq_scan2(sqOut, gridShade, 1, pool.qS, gridShade, shadowMult, 256, pool.totals, st);
                 uint32_t cnt[2] = {0, 0};
@@ -393,6 +436,13 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 std::swap(qin, qout);
                 std::swap(sqIn, sqOut);
                 n = cnt[0];
+                if (sortRays && n >= sortMin && n > tailMax && bounce + 1 < rp->max_bounces) {
+                    tm.nextItems = n;
+                    tm.begin(sortKind, st);
+                    if (launch_sort_queue(pool, sqIn, qin, n, ph->sortTemp, ph->sortTempBytes, st) != 0) return rtx_fail(RTX_ERR_HIP, "ray sort failed");
+                    tm.end(st);
+                    sortedNext = true;
+                }
                 if (n > 0 && n <= tailMax && bounce + 1 < rp->max_bounces) {
                     // few paths left: one kernel walks them to their ends (tail_kernel)
                     if (sidePending) {
@@ -443,8 +493,6 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     tm.flush();
     float total = 0.0f;
     (void)hipEventElapsedTime(&total, evTotal0, evTotal1);
-    (void)hipEventDestroy(evTotal0);
-    (void)hipEventDestroy(evTotal1);
     unsigned long long rc2[2] = {0, 0};   // [0] shadow hops, [1] closest-hit rays traced inside tail_kernel
     RTX_HIP(hipMemcpy(rc2, pool.rayCounters, sizeof(rc2), hipMemcpyDeviceToHost));
     out.rays_shadow = rc2[0];
@@ -485,14 +533,18 @@ int64_t rtx_refine_list(const rtx_pixel_stats* st, int width, int height, float 
     if (!st || !st->sum || !st->sum2 || width <= 0 || height <= 0) return rtx_fail(RTX_ERR_INVALID, "bad argument");
     if (rtx_device_count() <= 0) return rtx_fail(RTX_ERR_NO_DEVICE, "no HIP device present");
     const uint32_t n = (uint32_t)((size_t)width * height);
-    int* dList = nullptr;
-    uint32_t* dCount = nullptr;
-    RTX_HIP(hipMalloc((void**)&dList, (size_t)n * sizeof(int)));
-    if (hipMalloc((void**)&dCount, sizeof(uint32_t)) != hipSuccess) {
-        (void)hipFree(dList);
-        return rtx_fail(RTX_ERR_HIP, "hipMalloc failed");
-    }
-    (void)hipMemset(dCount, 0, sizeof(uint32_t));
+    // list + counter in one buffer that is kept between calls (an adaptive frame asks once per round)
+    static std::mutex mu;
+    static DevBuf scratch[64];
+    int dev = 0;
+    RTX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return rtx_fail(RTX_ERR_INVALID, "device index out of range");
+    std::lock_guard<std::mutex> lock(mu);
+    int rc = scratch[dev].ensure((size_t)n * sizeof(int) + 256);
+    if (rc != RTX_OK) return rc;
+    uint32_t* dCount = (uint32_t*)scratch[dev].p;
+    int* dList = (int*)((char*)scratch[dev].p + 256);
+    RTX_HIP(hipMemset(dCount, 0, sizeof(uint32_t)));
     PathPool view{};
     view.statSum = (float4*)st->sum;
     view.statSum2 = (float4*)st->sum2;
@@ -501,8 +553,6 @@ int64_t rtx_refine_list(const rtx_pixel_stats* st, int width, int height, float 
     hipError_t e = hipMemcpy(&cnt, dCount, sizeof(cnt), hipMemcpyDeviceToHost);
     std::vector<int> host(cnt);
     if (e == hipSuccess && cnt) e = hipMemcpy(host.data(), dList, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost);
-    (void)hipFree(dList);
-    (void)hipFree(dCount);
     if (e != hipSuccess) return rtx_fail(RTX_ERR_HIP, std::string("refine list: ") + hipGetErrorString(e));
     std::sort(host.begin(), host.end());   // the compaction order depends on wave scheduling; ranks must agree
     if (out_pixels) std::memcpy(out_pixels, host.data(), std::min(capacity, (size_t)cnt) * sizeof(int));

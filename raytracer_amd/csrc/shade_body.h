@@ -13,9 +13,9 @@
 __device__ __forceinline__ f3 apply_absorption(f3 c, f3 absorption, float dist) {   // RayCaster.cpp:281-301
     if (dist <= 0.0f) return c;
     if (absorption.x == 0.0f && absorption.y == 0.0f && absorption.z == 0.0f) return c;
-    const float ar = expf(-fmaxf(0.0f, absorption.x) * dist);
-    const float ag = expf(-fmaxf(0.0f, absorption.y) * dist);
-    const float ab = expf(-fmaxf(0.0f, absorption.z) * dist);
+    const float ar = rtx_expf(-fmaxf(0.0f, absorption.x) * dist);
+    const float ag = rtx_expf(-fmaxf(0.0f, absorption.y) * dist);
+    const float ab = rtx_expf(-fmaxf(0.0f, absorption.z) * dist);
     return mk3(fminf(c.x, c.x * ar), fminf(c.y, c.y * ag), fminf(c.z, c.z * ab));
 }
 __device__ __forceinline__ void dir_to_screen_uv(const DevCamera& cam, f3 dir, float& u, float& v) {   // :303-330
@@ -25,7 +25,7 @@ __device__ __forceinline__ void dir_to_screen_uv(const DevCamera& cam, f3 dir, f
     const float sx = dot3(dir, r) / dz;
     const float sy = dot3(dir, uvec) / dz;
     const float fovRad = cam.fov * PI_F / 180.0f;
-    const float halfY = tanf(0.5f * fovRad);
+    const float halfY = rtx_tanf(0.5f * fovRad);
     const float aspect = (cam.H > 0) ? (float)cam.W / (float)cam.H : 1.0f;
     const float halfX = halfY * aspect;
     const float ndcX = sx / halfX;

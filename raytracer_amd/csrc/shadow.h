@@ -67,7 +67,7 @@ __device__ __forceinline__ bool shadow_hop_end(const DevScene& sc, f3& o, f3 d, 
     cosTheta = fminf(fmaxf(cosTheta, 0.0f), 1.0f);
     float r0 = (etaI - etaT) / (etaI + etaT);
     r0 = r0 * r0;
-    const float F = r0 + (1.0f - r0) * powf(1.0f - cosTheta, 5.0f);
+    const float F = r0 + (1.0f - r0) * rtx_powf(1.0f - cosTheta, 5.0f);
     const float transmit = fmaxf(0.0f, fminf(1.0f, (1.0f - F) * transFactor));
     visibility *= fmaxf(0.0f, fminf(1.0f, transmit));
     if (visibility <= 1e-4f) return true;

@@ -60,8 +60,8 @@ __device__ __forceinline__ f3 tex_eval(const DevScene& sc, int tex, f3 uvw) {
 __device__ __forceinline__ f3 tex_eval_env(const DevScene& sc, int tex, f3 dir) {
     const DevTexMap& tm = sc.texmaps[tex];
     const f3 d = safe_normalize3(xf_vec3(tm.xf, dir));
-    const float u = atan2f(d.y, d.x) * (0.5f / 3.14159265358979323846f) + 0.5f;
-    const float v = acosf(fminf(1.0f, fmaxf(-1.0f, d.z))) * (1.0f / 3.14159265358979323846f);
+    const float u = rtx_atan2f(d.y, d.x) * (0.5f / 3.14159265358979323846f) + 0.5f;
+    const float v = rtx_acosf(fminf(1.0f, fmaxf(-1.0f, d.z))) * (1.0f / 3.14159265358979323846f);
     return tex_eval_raw(tm, mk3(u, v, 0.0f));
 }
 // TexturedColor::Eval: value * texture (or value alone)
@@ -90,10 +90,10 @@ __device__ __forceinline__ void resolve_analytic(const DevScene& sc, uint32_t ki
         GN = normalized3(hp);
         const f3 n = GN;
         const float PIf = 3.14159265358979323846f;
-        const float phi = atan2f(n.y, n.x);
-        const float theta = acosf(fminf(1.0f, fmaxf(-1.0f, n.z)));
+        const float phi = rtx_atan2f(n.y, n.x);
+        const float theta = rtx_acosf(fminf(1.0f, fmaxf(-1.0f, n.z)));
         uvw = mk3((phi + PIf) / (2.0f * PIf), 1.0f - (theta / PIf), 0.0f);
-        const float sinTheta = sinf(theta), cosTheta = cosf(theta), sinPhi = sinf(phi), cosPhi = cosf(phi);
+        const float sinTheta = rtx_sinf(theta), cosTheta = rtx_cosf(theta), sinPhi = rtx_sinf(phi), cosPhi = rtx_cosf(phi);
         dpdu = mk3(-sinTheta * sinPhi * 2.0f * PIf, sinTheta * cosPhi * 2.0f * PIf, 0.0f);
         dpdv = mk3(-PIf * cosTheta * cosPhi, -PIf * cosTheta * sinPhi, PIf * sinTheta);
     } else {

@@ -2,6 +2,7 @@
 // that must reproduce an fp32 CPU evaluation bit for bit switch contraction off locally.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "rtx_math.h"   // powf, sinf ... of the path: the same routines the CPU oracle evaluates
 
 struct f3 {
     float x, y, z;

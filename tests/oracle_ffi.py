@@ -8,7 +8,8 @@ import numpy as np
 from raytracer_amd import _ffi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "oracle", "liboracle.so")
+# ORACLE_LIB selects another build of the oracle (A/B runs of experimental variants)
+LIB = os.environ.get("ORACLE_LIB") or os.path.join(ROOT, "oracle", "liboracle.so")
 _lib = None
 _vp = C.c_void_p
 
