@@ -403,11 +403,11 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
         o.flags = ((md.vn && md.nvn > 0) ? OBJ_HAS_NORMALS : 0u) | ((md.vt && md.nvt > 0) ? OBJ_HAS_TEXCOORDS : 0u);
         // The reference intersects in object space (IntersectNodeAdapter.h:62,93): a mesh under a non-identity transform
         // keeps its object-space vertices (RTX_KIND_XFTRI records); only its BVH boxes are in world space
-        if (md.kind == RTX_OBJ_MESH && !ident) o.flags |= OBJ_TRANSFORMED;
+        if (md.kind == RTX_OBJ_MESH && !ident) o.flags |= OBJ_TRANSFORMED | OBJ_XFMESH;
         o.face_base = faceBase[m];
         if (md.kind != RTX_OBJ_MESH) {
             // Sphere: GetBoundBox = [-1,1]^3, Plane: [-1,1]^2 x {0}; corners to root coordinates
-            o.flags = OBJ_HAS_TEXCOORDS;
+            o.flags = OBJ_HAS_TEXCOORDS | (ident ? 0u : OBJ_TRANSFORMED);
             o.nf = 1;
             AABB wb;
             for (int c = 0; c < 8; ++c) {

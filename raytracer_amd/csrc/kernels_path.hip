@@ -369,7 +369,11 @@ __global__ void film_kernel(PathPool pool, rtx_film film, const int* __restrict_
             const float4 al = pool.albedo[slot];
             if (al.w != 0.0f) {
                 guide = true;
-                const float4 nn = pool.normal[slot];
+                float4 nn = pool.normal[slot];
+                {   // StoreGuide normalises the path's (already unit) normal once more (RayCaster.cpp:713)
+                    const f3 n2 = safe_normalize3(mk3(nn.x, nn.y, nn.z));
+                    nn.x = n2.x; nn.y = n2.y; nn.z = n2.z;
+                }
                 float* A = film.albedo + 4 * (size_t)pix;
                 A[0] = al.x; A[1] = al.y; A[2] = al.z; A[3] = 1.0f;
                 if (film.normal) {

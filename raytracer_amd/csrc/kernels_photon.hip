@@ -3,6 +3,7 @@
 // probes. One lane follows one photon through its <= maxBounces+1 segments; lanes pull photon ids 64 at a time.
 #include "kernels.h"
 #include "photon.h"
+#include "photon_cell.h"
 #include "bsdf.h"
 #include "shadow.h"
 #include "photon_gather.h"
@@ -129,26 +130,10 @@ __global__ __launch_bounds__(TRAV_BLOCK) void photon_emit_kernel(DevScene scArg,
     atomicAdd(&counts[3], segments);
 }
 
-__device__ __forceinline__ uint32_t cell_of(const PhotonSet& s, float4 p) {
-    const int cx = min(s.gx - 1, max(0, (int)((p.x - s.gmin[0]) / s.cell)));
-    const int cy = min(s.gy - 1, max(0, (int)((p.y - s.gmin[1]) / s.cell)));
-    const int cz = min(s.gz - 1, max(0, (int)((p.z - s.gmin[2]) / s.cell)));
-    return (uint32_t)(((size_t)cz * s.gy + cy) * s.gx + cx);
-}
 __global__ void photon_count_kernel(PhotonSet s, uint32_t* __restrict__ cellCount) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= s.n) return;
     atomicAdd(&cellCount[cell_of(s, s.raw[i].pos)], 1u);
-}
-// counting-sort scatter; cursor[c] starts at cellStart[c]. Power is scaled here (PhotonMapBuilder.cpp:38-50).
-__global__ void photon_scatter_kernel(PhotonSet s, uint32_t* __restrict__ cursor, float scale) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= s.n) return;
-    const DevPhotonRec r = s.raw[i];
-    const uint32_t k = atomicAdd(&cursor[cell_of(s, r.pos)], 1u);
-    s.pos[k] = r.pos;
-    s.dir[k] = r.dir;
-    s.power[k] = make_float4(r.power.x * scale, r.power.y * scale, r.power.z * scale, 0.0f);
 }
 __global__ void photon_probe_kernel(DevPhotonMap pm, const float* __restrict__ pos, const float* __restrict__ nrm, uint32_t n,
                                     float* __restrict__ out) {
@@ -176,10 +161,6 @@ void launch_photon_emit(const DevScene& sc, const LaunchCfg& cfg, int numPhotons
 void launch_photon_count(const PhotonSet& s, uint32_t* cellCount, hipStream_t st) {
     if (!s.n) return;
     hipLaunchKernelGGL(photon_count_kernel, dim3((s.n + 255) / 256), dim3(256), 0, st, s, cellCount);
-}
-void launch_photon_scatter(const PhotonSet& s, uint32_t* cursor, float scale, hipStream_t st) {
-    if (!s.n) return;
-    hipLaunchKernelGGL(photon_scatter_kernel, dim3((s.n + 255) / 256), dim3(256), 0, st, s, cursor, scale);
 }
 void launch_photon_probe(const DevPhotonMap& pm, const float* pos, const float* nrm, uint32_t n, float* out, hipStream_t st) {
     if (!n) return;

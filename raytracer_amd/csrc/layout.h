@@ -65,7 +65,8 @@ static_assert(sizeof(TriAttr) == 64, "TriAttr must be 64 bytes");
 
 #define OBJ_HAS_NORMALS 1u
 #define OBJ_HAS_TEXCOORDS 2u
-#define OBJ_TRANSFORMED 8u   // the object's transform is not the identity: its triangles stay in object space (RTX_KIND_XFTRI)
+#define OBJ_TRANSFORMED 8u   // the object's node transform is not the identity (ToNodeCoords / FromNodeCoords apply)
+#define OBJ_XFMESH 16u       // ... and it is a mesh: its triangles stay in object space (RTX_KIND_XFTRI records)
 struct ObjRec {
     int material;           // index into materials, -1 = none
     uint32_t flags;

@@ -9,7 +9,7 @@
 void launch_photon_emit(const DevScene& sc, const LaunchCfg& cfg, int numPhotons, int first, int stride, int maxBounces,
                         unsigned long long seed, DevPhotonRec* g, uint32_t gcap, DevPhotonRec* c, uint32_t ccap, uint32_t* counts);
 void launch_photon_count(const PhotonSet& s, uint32_t* cellCount, hipStream_t st);
-void launch_photon_scatter(const PhotonSet& s, uint32_t* cursor, float scale, hipStream_t st);
+int launch_photon_order(const PhotonSet& s, float scale, hipStream_t st);   // kernels_sort.hip
 void launch_photon_probe(const DevPhotonMap& pm, const float* pos, const float* nrm, uint32_t n, float* out, hipStream_t st);
 
 void photon_device_map(const rtx_photons* p, int which, DevPhotonMap& out) {
@@ -39,7 +39,8 @@ static void free_sorted(PhotonSet& s) {
     s.cellStart = nullptr;
 }
 
-// Scale powers, bin the photons into a uniform grid of cell edge >= radius over the scene box (counting sort).
+// Scale powers, bin the photons into a uniform grid of cell edge >= radius over the scene box (cell counts + a radix
+// sort by (cell, photon key)).
 static int finalize_set(rtx_photons* p, int which, float scale) {
     PhotonSet& s = p->set[which];
     free_sorted(s);
@@ -75,10 +76,10 @@ static int finalize_set(rtx_photons* p, int which, float scale) {
         run += c;
     }
     RTX_HIP(hipMemcpy(s.cellStart, cnt.data(), (s.cells + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
-    RTX_HIP(hipMemcpy(cursor, cnt.data(), (s.cells + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
-    launch_photon_scatter(s, cursor, scale, nullptr);
-    RTX_HIP(hipDeviceSynchronize());
     (void)hipFree(cursor);
+    // records in (cell, photon key) order: the same map whatever order the emit kernel's lanes stored them in
+    if (launch_photon_order(s, scale, nullptr) != 0) return rtx_fail(RTX_ERR_HIP, "ordering the photon map failed");
+    RTX_HIP(hipDeviceSynchronize());
     return RTX_OK;
 }
 

@@ -103,15 +103,21 @@ __device__ __forceinline__ void resolve_analytic(const DevScene& sc, uint32_t ki
         dpdv = mk3(0.0f, 2.0f, 0.0f);
     }
     s.front = kind == RTX_OBJ_SPHERE ? (d[0] * GN.x + d[1] * GN.y + d[2] * GN.z) < 0.0f : d[2] < 0.0f;
+    // FromNodeCoords (IntersectNodeAdapter.h:93) applies to non-identity nodes only: under the identity the reference keeps
+    // the object-space values as they are (renormalising a unit normal again can move its last bit). Written as selects:
+    // the identity matrices give the same p / dpdu / dpdv bit for bit, only the renormalised normal needs the choice.
+    const bool xf = (sc.objs[obj].flags & OBJ_TRANSFORMED) != 0u;
     const ObjXform& X = sc.objXf[obj];
     const float* F = X.fwd;
     const float* I = X.inv;
-    s.p = xf_point3(F, hp);
-    s.GN = normalized3(mk3(I[0] * GN.x + I[4] * GN.y + I[8] * GN.z, I[1] * GN.x + I[5] * GN.y + I[9] * GN.z,
-                           I[2] * GN.x + I[6] * GN.y + I[10] * GN.z));
+    const f3 GNw = normalized3(mk3(I[0] * GN.x + I[4] * GN.y + I[8] * GN.z, I[1] * GN.x + I[5] * GN.y + I[9] * GN.z,
+                                   I[2] * GN.x + I[6] * GN.y + I[10] * GN.z));
+    const f3 pw = xf_point3(F, hp), duw = xf_vec3(F, dpdu), dvw = xf_vec3(F, dpdv);
+    s.p = xf ? pw : hp;
+    s.GN = xf ? GNw : GN;
+    s.dpdu = xf ? duw : dpdu;
+    s.dpdv = xf ? dvw : dpdv;
     s.N = s.GN;
-    s.dpdu = xf_vec3(F, dpdu);
-    s.dpdv = xf_vec3(F, dpdv);
     s.uvw = uvw;
     s.t = h.t;
     s.obj = (int)obj;

@@ -5,7 +5,7 @@ import pytest
 
 from raytracer_amd import _ffi, synth
 from raytracer_amd.scene import SceneData, Mesh, Material, Light, make_camera, render_params
-from tests.helpers import random_rays, compare_hits
+from tests.helpers import assert_path_samples_identical, random_rays, compare_hits
 from tests.oracle_ffi import OracleScene
 
 pytestmark = pytest.mark.gpu
@@ -42,20 +42,17 @@ def test_closest_hit_with_spheres_and_planes(mixed, side):
     rays = random_rays(np.random.default_rng(21), 40000, osc.bounds())
     g = gs.trace_closest(rays, side)
     o = osc.trace_closest(rays, side)
-    same, hit = compare_hits(g, o, gs.face_base, id_tol=2e-3, t_rel=1e-4)
+    same, hit = compare_hits(g, o, gs.face_base)
+    assert same.all() and np.array_equal(g["t"][hit], o["t"][hit])
     kinds = np.array([m.kind for m in sd.meshes])
     analytic = hit & (kinds[np.maximum(g["obj"], 0)] != _ffi.OBJ_MESH)
     assert analytic.sum() > 2000
     # HitInfo of the analytic hits (world space after FromNodeCoords)
-    for k, tol in (("p", 1e-4), ("N", 1e-4), ("GN", 1e-4), ("uvw", 2e-4), ("dpdu", 2e-3), ("dpdv", 2e-3)):
-        d = np.abs(g[k][analytic] - o[k][analytic])
-        if k == "uvw":   # u wraps at the sphere's seam
-            d[:, 0] = np.minimum(d[:, 0], 1.0 - d[:, 0])
-        assert d.max() <= tol * max(1.0, np.abs(o[k][analytic]).max()), (k, d.max())
+    for k in ("p", "N", "GN", "uvw", "dpdu", "dpdv"):   # same operations, same elementary functions (rtx_math.h): bit-identical
+        assert np.array_equal(g[k][analytic], o[k][analytic]), (k, np.abs(g[k][analytic] - o[k][analytic]).max())
     assert (g["front"][analytic] == o["front"][analytic]).all()
     # the object-space test keeps t within 1e-5 on the analytic objects themselves
-    rel = np.abs(g["t"][analytic] - o["t"][analytic]) / o["t"][analytic]
-    assert rel.max() <= 1e-5
+    assert np.array_equal(g["t"][analytic], o["t"][analytic])
 
 
 def test_visibility_through_analytic_glass(mixed):
@@ -66,7 +63,7 @@ def test_visibility_through_analytic_glass(mixed):
     for tr in (True, False):
         g = gs.trace_visibility(rays, normals, tr)
         o = osc.trace_visibility(rays, normals, tr)
-        assert (np.abs(g - o) <= 1e-5).mean() >= 0.999
+        assert np.array_equal(g, o)
 
 
 def test_path_tracing_with_analytic_objects(mixed):
@@ -76,9 +73,6 @@ def test_path_tracing_with_analytic_objects(mixed):
     g, _ = gs.render_samples(cam, rp)
     o = osc.render_samples(cam, rp)
     assert np.isfinite(g).all()
-    pd_ok = np.abs(g[..., 3] - o[..., 3]) <= 1e-4 * np.abs(o[..., 3])
-    assert pd_ok.mean() >= 0.999
-    d = np.abs(g[..., :3] - o[..., :3]).max(-1)
-    ok = d <= 1e-3 * (1 + np.abs(o[..., :3]).max(-1))
-    assert ok.mean() >= 0.99, ok.mean()
+    assert np.array_equal(g[..., 3], o[..., 3])
+    assert_path_samples_identical(g, o)
     assert o[..., :3].mean() > 0.01

@@ -5,6 +5,7 @@ import pytest
 
 from raytracer_amd import _ffi, synth
 from raytracer_amd.scene import SceneData, Mesh, Material, Light, make_camera, render_params
+from tests.helpers import assert_path_samples_identical
 from tests.oracle_ffi import OracleScene, OraclePhotons
 
 pytestmark = pytest.mark.gpu
@@ -40,12 +41,9 @@ def test_per_sample_radiance(scene, max_bounces):
     g, _ = gs.render_samples(cam, rp)
     o = osc.render_samples(cam, rp)
     assert np.isfinite(g).all()
-    d = np.abs(g[..., :3] - o[..., :3]).max(-1)
-    ok = d <= 1e-3 * (1 + np.abs(o[..., :3]).max(-1))
-    assert ok.mean() >= 0.995, ok.mean()
+    assert_path_samples_identical(g, o)
     assert o[..., :3].mean() > 0.02
-    rmse = np.sqrt(np.mean((g[..., :3].mean(2) - o[..., :3].mean(2)) ** 2))
-    assert rmse <= 0.02 * o[..., :3].mean()
+    assert np.array_equal(g[..., 3], o[..., 3])
 
 
 def test_photons_through_microfacet_glass(scene, rtx):

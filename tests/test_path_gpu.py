@@ -1,19 +1,18 @@
 """GPU parity of the light-transport path (ray-gen, extend, shade, shadow, resolve, film, adaptive rounds) against
 the CPU oracle, through the C ABI. Same sampler sequence and the same counter-based RNG on both sides.
 
-Tolerances (fp32; stated per north_star): hit distances 1e-5 relative; per-sample radiance within 1e-4 * (1 + |ref|)
-on at least 99.99 % of samples for direct lighting and 99.5 % for the 64-bounce path loop (measured, IEEE division on
-both sides: 99.998 % / 99.75-99.8 %, tools/parity_levels.py; the rest are paths whose branch decisions flip on the last
-bit of a libm result - the GPU's powf/expf/sinf are not glibc's: powf with the scene's gloss 1e5 amplifies one ulp of
-N.H to ~1 %, and a glass path that takes the other lobe is a different path); per-pixel image RMSE <= 2 % of the mean
-radiance at equal spp.
+Bars (fp32): per-sample radiance and primary distance BIT-IDENTICAL to the oracle, at every depth - both sides
+evaluate the same IEEE operations in the same order, the elementary functions included (raytracer_amd/csrc/rtx_math.h;
+with the GPU's own powf / sinf against glibc's, 0.2 % of the samples of this scene parted from the oracle at 64 bounces:
+a last-bit difference in the Blinn lobe is a different path a few bounces later). Film sums are float atomics in
+scheduling order: accumulated images are compared with a per-pixel tolerance (RMSE <= 1e-5 of the mean radiance).
 """
 import numpy as np
 import pytest
 
 from raytracer_amd import _ffi, synth
 from raytracer_amd.scene import render_params
-from tests.helpers import random_rays
+from tests.helpers import random_rays, assert_path_samples_identical, exact_fraction
 from tests.oracle_ffi import OracleScene
 
 pytestmark = pytest.mark.gpu
@@ -44,11 +43,8 @@ def test_per_sample_radiance(small, max_bounces):
     g, st = gs.render_samples(cam, rp)
     o = osc.render_samples(cam, rp)
     assert np.isfinite(g).all()
-    # primary distance (first extend + thin-lens ray generation): 1e-5 relative
-    pd_ok = np.abs(g[..., 3] - o[..., 3]) <= 1e-5 * np.abs(o[..., 3])
-    assert pd_ok.mean() >= 0.9999
-    assert frac_within(g, o) >= BAR[max_bounces]
-    assert frac_within(g, o, 1e-3) >= 0.998
+    assert np.array_equal(g[..., 3], o[..., 3])              # primary distance (thin-lens ray generation + first extend)
+    assert_path_samples_identical(g, o)
     assert st["rays_primary"] == cam.width * cam.height * 8
     assert (g[..., :3] <= 10.0).all()                      # kRadianceClamp
 
@@ -59,14 +55,16 @@ def test_image_film_z_counts(small):
     g = gs.render(cam, rp)
     o = osc.render(cam, rp)
     rmse = np.sqrt(np.mean((g["linear"] - o["linear"]) ** 2))
-    assert rmse <= 0.02 * o["linear"].mean(), rmse
+    assert rmse <= 1e-5 * o["linear"].mean(), rmse                    # same samples; the film sums them in another order
+    assert np.allclose(g["linear"], o["linear"], rtol=2e-5, atol=2e-6)
     assert np.array_equal(g["samples"], o["samples"]) and (g["samples"] == 16).all()
-    assert (np.abs(g["z"] - o["z"]) <= 1e-5 * np.abs(o["z"])).mean() >= 0.9999
-    assert (np.abs(g["rgb8"].astype(int) - o["rgb8"].astype(int)) <= 1).mean() >= 0.97
+    assert np.array_equal(g["z"], o["z"])
+    assert (np.abs(g["rgb8"].astype(int) - o["rgb8"].astype(int)) <= 1).all()     # a value within rounding of a level boundary
+    assert (g["rgb8"] == o["rgb8"]).mean() >= 0.999
     # rays actually traced: primary and bounce counts agree with the oracle to within path-divergence noise; the GPU
     # traces no shadow ray for light samples whose BSDF contribution is exactly zero
     assert g["stats"]["rays_primary"] == o["rays"]["primary"]
-    assert abs(g["stats"]["rays_bounce"] - o["rays"]["bounce"]) <= 0.002 * o["rays"]["bounce"]
+    assert g["stats"]["rays_bounce"] == o["rays"]["bounce"]              # identical paths: identical ray counts
     assert 0 < g["stats"]["rays_shadow"] <= o["rays"]["shadow"]
 
 
@@ -77,7 +75,7 @@ def test_filters_and_pass_size_independence(small, rtx):
         rp = render_params(spp_min=4, max_bounces=2, filter_type=ft, filter_radius=rad)
         g, o = gs.render(cam, rp), osc.render(cam, rp)
         rmse = np.sqrt(np.mean((g["linear"] - o["linear"]) ** 2))
-        assert rmse <= 0.02 * np.abs(o["linear"]).mean(), (ft, rmse)
+        assert rmse <= 1e-5 * np.abs(o["linear"]).mean(), (ft, rmse)
     a, _ = gs.render_samples(cam, render_params(spp_min=6, max_bounces=8, samples_per_pass=1))
     b, _ = gs.render_samples(cam, render_params(spp_min=6, max_bounces=8, samples_per_pass=4))
     c, _ = gs.render_samples(cam, render_params(spp_min=6, max_bounces=8, samples_per_pass=6))
@@ -90,11 +88,11 @@ def test_adaptive_sample_maps(small):
     rp = render_params(spp_min=8, spp_max=32, max_bounces=8, ci_halfwidth=0.02)
     g, o = gs.render(cam, rp), osc.render(cam, rp)
     assert set(np.unique(g["samples"])) <= {8, 16, 24, 32}
-    assert (g["samples"] == o["samples"]).mean() >= 0.995
+    assert np.array_equal(g["samples"], o["samples"])              # identical samples: identical refinement decisions
     assert (g["samples"] > 8).any() and (g["samples"] == 8).any()
     rmse = np.sqrt(np.mean((g["linear"] - o["linear"]) ** 2))
-    assert rmse <= 0.02 * o["linear"].mean()
-    assert (np.abs(g["z"] - o["z"]) <= 1e-5 * np.abs(o["z"])).mean() >= 0.999
+    assert rmse <= 1e-5 * o["linear"].mean()
+    assert np.array_equal(g["z"], o["z"])
 
 
 def test_visibility_chains(small):
@@ -105,7 +103,7 @@ def test_visibility_chains(small):
     nrm = rng.normal(size=(30000, 3)).astype(np.float32)
     for ut in (True, False):
         gv, ov = gs.trace_visibility(rays, nrm, ut), osc.trace_visibility(rays, nrm, ut)
-        assert (np.abs(gv - ov) <= 1e-5).mean() >= 0.9999
+        assert np.array_equal(gv, ov)
     part = osc.trace_visibility(rays, nrm, True)
     assert ((part > 0) & (part < 1)).sum() > 20            # transmissive chains are exercised
 
@@ -136,8 +134,8 @@ def test_tile_sharding_sums_to_full_frame(small, rtx):
     res = rtx.film_resolve(_ffi.Film(*[x.data_ptr() for x in full]), cam, want_aov=True)
     o = osc.render(cam, render_params(spp_min=4, max_bounces=8))
     hit = o["albedo"][..., 3] > 0
-    assert np.abs(res["albedo"][hit] - o["albedo"][..., :3][hit]).max() <= 1e-4     # first-hit guides (RayCaster.cpp:709-714)
-    assert np.abs(res["normal"][hit] - o["normal"][..., :3][hit]).max() <= 1e-4
+    assert np.array_equal(res["albedo"][hit], o["albedo"][..., :3][hit])            # first-hit guides (RayCaster.cpp:709-714)
+    assert np.array_equal(res["normal"][hit], o["normal"][..., :3][hit])
 
 
 def test_golden_path_fixture(rtx):
@@ -147,9 +145,9 @@ def test_golden_path_fixture(rtx):
     cam = synth.cerealbar_camera(48, 27)
     gs = rtx.Scene(sd)
     s, _ = gs.render_samples(cam, render_params(spp_min=4, max_bounces=64))
-    assert frac_within(s, g["samples"]) >= 0.995 and frac_within(s, g["samples"], 1e-3) >= 0.998
+    assert_path_samples_identical(s, g["samples"])
     ada = gs.render(cam, render_params(spp_min=8, spp_max=32, max_bounces=8, ci_halfwidth=0.02))
-    assert (ada["samples"] == g["adaptive_samples"]).mean() >= 0.995
+    assert np.array_equal(ada["samples"], g["adaptive_samples"])
 
 
 def test_error_paths(small, rtx):
@@ -199,5 +197,8 @@ def test_textured_glossiness(rtx, mode):
     gs, osc = rtx.Scene(sd), OracleScene(sd)
     g, _ = gs.render_samples(cam, rp)
     o = osc.render_samples(cam, rp)
-    assert frac_within(g, o) >= 0.995 and frac_within(g, o, 1e-3) >= 0.997
+    if mode == _ffi.SHADING_PATH:
+        assert_path_samples_identical(g, o)
+    else:
+        assert frac_within(g, o, 1e-5) >= 0.9999                # the legacy kernel sums a sample's recursion tree in another order
     assert np.abs(g[..., :3] - plain[..., :3]).mean() > 1e-4   # the map does change the highlights

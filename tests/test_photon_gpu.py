@@ -68,7 +68,7 @@ def test_caustic_term_in_path_loop(env):
     g, _ = gs.render_samples(cam, rp, gp)
     o = osc.render_samples(cam, rp, op)
     d = np.abs(g[..., :3] - o[..., :3]).max(-1)
-    assert (d <= 2e-3 * (1 + np.abs(o[..., :3]).max(-1))).mean() >= 0.99
+    assert (d <= 1e-5 * (1 + np.abs(o[..., :3]).max(-1))).mean() >= 0.999
     base = osc.render_samples(cam, render_params(spp_min=4, max_bounces=4))
     assert np.abs(o[..., :3] - base[..., :3]).max() > 1e-4      # the caustic map does contribute
 

@@ -6,6 +6,7 @@ import pytest
 
 from raytracer_amd import _ffi
 from raytracer_amd.scene import Light, Material, Mesh, SceneData, make_camera, render_params
+from tests.helpers import assert_path_samples_identical, assert_legacy_samples_close
 from tests.oracle_ffi import OracleScene
 
 pytestmark = pytest.mark.gpu
@@ -49,6 +50,14 @@ def agree(g, o, tol=1e-3):
     return float((d <= tol * (1 + np.abs(o[..., :3]).max(-1))).mean())
 
 
+def check(g, o, mode=_ffi.SHADING_PATH):
+    """Path mode: bit-identical to the oracle. Legacy mode: the kernel sums a sample's recursion tree in another order."""
+    if mode == _ffi.SHADING_PATH:
+        assert_path_samples_identical(g, o)
+    else:
+        assert_legacy_samples_close(g, o)
+
+
 @pytest.mark.parametrize("w,h", [(1, 1), (7, 5), (33, 17), (70, 50)])
 def test_odd_image_sizes(rtx, w, h):
     sd = room()
@@ -58,10 +67,11 @@ def test_odd_image_sizes(rtx, w, h):
     g, st = gs.render_samples(cam, rp)
     o = osc.render_samples(cam, rp)
     assert g.shape == o.shape == (h, w, 3, 4) and st["rays_primary"] == w * h * 3
-    assert agree(g, o) >= 0.99 and np.isfinite(g).all()
+    assert np.isfinite(g).all()
+    check(g, o)
     img, ref = gs.render(cam, rp), osc.render(cam, rp)
     assert np.array_equal(img["samples"], ref["samples"])
-    assert np.abs(img["linear"] - ref["linear"]).mean() <= 0.02 * (ref["linear"].mean() + 1e-3)
+    assert np.allclose(img["linear"], ref["linear"], rtol=2e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("mode", [_ffi.SHADING_PATH, _ffi.SHADING_LEGACY])
@@ -74,7 +84,8 @@ def test_light_counts(rtx, mode, n_lights):
     rp = render_params(spp_min=4, max_bounces=12, shading_mode=mode)
     g, st = gs.render_samples(cam, rp)
     o = osc.render_samples(cam, rp)
-    assert np.isfinite(g).all() and agree(g, o) >= 0.99
+    assert np.isfinite(g).all()
+    check(g, o, mode)
     assert (st["rays_shadow"] == 0) == (n_lights == 0)
 
 
@@ -93,11 +104,8 @@ def test_scene_scale(rtx, scale):
         g, _ = gs.render_samples(cam, rp)
         o = osc.render_samples(cam, rp)
         assert np.isfinite(g).all()
-        assert (np.abs(g[..., 3] - o[..., 3]) <= 1e-4 * np.abs(o[..., 3])).mean() >= 0.995
-        if scale < 1e3:   # at 1e2 an ulp of the coordinates (3e-5) is already a third of the offsets: a few more flips
-            assert agree(g, o, 2e-3) >= (0.985 if scale < 50 else 0.97), (scale, mode)
-        else:
-            assert abs(g[..., :3].mean() - o[..., :3].mean()) <= 0.25 * o[..., :3].mean(), (scale, mode)
+        assert np.array_equal(g[..., 3], o[..., 3])
+        check(g, o, mode)   # ill-conditioned or not, both sides make the same last-bit decisions
 
 
 def test_all_glass_long_paths(rtx):
@@ -109,7 +117,8 @@ def test_all_glass_long_paths(rtx):
         rp = render_params(spp_min=4, max_bounces=mb)
         g, st = gs.render_samples(cam, rp)
         o = osc.render_samples(cam, rp)
-        assert np.isfinite(g).all() and agree(g, o, 2e-3) >= 0.985, mb
+        assert np.isfinite(g).all()
+        check(g, o)
     assert st["rays_bounce"] > st["rays_primary"] // 2 and st["rays_shadow"] > 0
 
 
