@@ -1342,24 +1342,49 @@ void PhotonMap::scale(float s) {
         for (int k = 0; k < 3; ++k) p.power[k] *= s;
 }
 
+// Stand-in for cyPhotonMap's balanced kd-tree (absent): a uniform grid. The grid is a window of the lattice
+// floor(p / cell) anchored at the origin; its edge is the search radius, doubled until the photons' bounding box spans
+// at most 512 cells per axis and 2^24 in all. Photons are kept cell by cell and, inside a cell, in emission order
+// ((photon, bounce) ascending). This fixes the order of the floating-point sum in estimate() below.
+static int lattice_clamped(float x, float cell, int imin, int g) {
+    return (int)std::fmin(std::fmax(std::floor(x / cell) - (float)imin, 0.0f), (float)(g - 1));
+}
+
 void PhotonMap::prepare(float radius) {
     cellStart.clear();
     order.clear();
     if (ph.empty()) return;
     Box b;
     for (auto& p : ph) b.add(V3(p.pos[0], p.pos[1], p.pos[2]));
+    const float lo[3] = {b.pmin.x, b.pmin.y, b.pmin.z}, hi[3] = {b.pmax.x, b.pmax.y, b.pmax.z};
     cell = std::max(radius, 1e-6f);
-    gmin = b.pmin;
-    V3 e = b.pmax - b.pmin;
-    auto dim = [&](float ext) { return std::max(1, std::min(1024, (int)(ext / cell) + 1)); };
-    gx = dim(e.x);
-    gy = dim(e.y);
-    gz = dim(e.z);
+    for (;; cell *= 2.0f) {
+        double total = 1.0;
+        bool ok = true;
+        for (int a = 0; a < 3; ++a) {
+            const float f0 = std::floor(lo[a] / cell), f1 = std::floor(hi[a] / cell);
+            const double d = (double)f1 - (double)f0 + 1.0;
+            if (!(d <= 512.0) || !(std::fabs(f0) < 4194304.0f) || !(std::fabs(f1) < 4194304.0f)) ok = false;
+            total *= d;
+        }
+        if (ok && total <= 16777216.0) break;
+        if (!(cell < 1e30f)) {   // non-finite positions: one cell
+            break;
+        }
+    }
+    int g[3];
+    for (int a = 0; a < 3; ++a) {
+        imin[a] = (int)std::floor(lo[a] / cell);
+        g[a] = std::max(1, (int)std::floor(hi[a] / cell) - imin[a] + 1);
+    }
+    gx = g[0];
+    gy = g[1];
+    gz = g[2];
     std::vector<int> cnt((size_t)gx * gy * gz + 1, 0);
     auto cellOf = [&](const rtx_photon& p) {
-        int cx = std::min(gx - 1, std::max(0, (int)((p.pos[0] - gmin.x) / cell)));
-        int cy = std::min(gy - 1, std::max(0, (int)((p.pos[1] - gmin.y) / cell)));
-        int cz = std::min(gz - 1, std::max(0, (int)((p.pos[2] - gmin.z) / cell)));
+        const int cx = lattice_clamped(p.pos[0], cell, imin[0], gx);
+        const int cy = lattice_clamped(p.pos[1], cell, imin[1], gy);
+        const int cz = lattice_clamped(p.pos[2], cell, imin[2], gz);
         return ((size_t)cz * gy + cy) * gx + cx;
     };
     for (auto& p : ph) cnt[cellOf(p) + 1]++;
@@ -1367,13 +1392,14 @@ void PhotonMap::prepare(float radius) {
     cellStart = cnt;
     order.resize(ph.size());
     std::vector<int> fill(cnt.begin(), cnt.end() - 1);
-    for (size_t i = 0; i < ph.size(); ++i) order[fill[cellOf(ph[i])]++] = (int)i;
+    for (size_t i = 0; i < ph.size(); ++i) order[fill[cellOf(ph[i])]++] = (int)i;   // ascending index inside a cell
 }
 
 // PhotonMap::EstimateIrradiance<maxPhotons, PHOTONMAP_FILTER_LINEAR> (cyPhotonMap, absent). Stand-in
 // definition: the k nearest photons within `radius` (ties by index); r = distance of the k-th when
 // k were found, else `radius`; photons arriving against the normal (dir.N < 0) weighted by the cone filter
-// 1 - d/r; normalisation 1 / ((1 - 2/3) pi r^2).
+// 1 - d/r; normalisation 1 / ((1 - 2/3) pi r^2). The sum runs over the selected photons in the order of the grid
+// (cells z-major, then y, then x; inside a cell by index).
 V3 PhotonMap::estimate(int maxPhotons, float radius, V3 pos, V3 normal) const {
     if (ph.empty() || order.empty()) return V3(0, 0, 0);
     struct Cand {
@@ -1382,11 +1408,9 @@ V3 PhotonMap::estimate(int maxPhotons, float radius, V3 pos, V3 normal) const {
     };
     std::vector<Cand> cand;
     float r2 = radius * radius;
-    int cx0 = (int)std::floor((pos.x - radius - gmin.x) / cell), cx1 = (int)std::floor((pos.x + radius - gmin.x) / cell);
-    int cy0 = (int)std::floor((pos.y - radius - gmin.y) / cell), cy1 = (int)std::floor((pos.y + radius - gmin.y) / cell);
-    int cz0 = (int)std::floor((pos.z - radius - gmin.z) / cell), cz1 = (int)std::floor((pos.z + radius - gmin.z) / cell);
-    cx0 = std::max(cx0, 0); cy0 = std::max(cy0, 0); cz0 = std::max(cz0, 0);
-    cx1 = std::min(cx1, gx - 1); cy1 = std::min(cy1, gy - 1); cz1 = std::min(cz1, gz - 1);
+    const int cx0 = lattice_clamped(pos.x - radius, cell, imin[0], gx), cx1 = lattice_clamped(pos.x + radius, cell, imin[0], gx);
+    const int cy0 = lattice_clamped(pos.y - radius, cell, imin[1], gy), cy1 = lattice_clamped(pos.y + radius, cell, imin[1], gy);
+    const int cz0 = lattice_clamped(pos.z - radius, cell, imin[2], gz), cz1 = lattice_clamped(pos.z + radius, cell, imin[2], gz);
     for (int cz = cz0; cz <= cz1; ++cz)
         for (int cy = cy0; cy <= cy1; ++cy)
             for (int cx = cx0; cx <= cx1; ++cx) {
@@ -1401,16 +1425,18 @@ V3 PhotonMap::estimate(int maxPhotons, float radius, V3 pos, V3 normal) const {
     if (cand.empty()) return V3(0, 0, 0);
     auto less = [](const Cand& a, const Cand& b) { return a.d2 < b.d2 || (a.d2 == b.d2 && a.idx < b.idx); };
     float rr2 = r2;
-    if ((int)cand.size() > maxPhotons) {
-        std::nth_element(cand.begin(), cand.begin() + maxPhotons, cand.end(), less);
-        cand.resize(maxPhotons);
+    Cand last{r2, 0x7FFFFFFF};   // the k-th nearest: everything up to it is selected
+    if ((int)cand.size() >= maxPhotons) {
+        std::vector<Cand> sel(cand);
+        std::nth_element(sel.begin(), sel.begin() + (maxPhotons - 1), sel.end(), less);
+        last = sel[maxPhotons - 1];
+        rr2 = last.d2;
     }
-    std::sort(cand.begin(), cand.end(), less);
-    if ((int)cand.size() == maxPhotons) rr2 = cand.back().d2;
     if (rr2 <= 0.0f) return V3(0, 0, 0);
     float r = std::sqrt(rr2);
     V3 irrad(0, 0, 0);
-    for (auto& c : cand) {
+    for (auto& c : cand) {   // grid order
+        if (less(last, c)) continue;
         const rtx_photon& p = ph[c.idx];
         if (dot(V3(p.dir[0], p.dir[1], p.dir[2]), normal) >= 0.0f) continue;
         float w = 1.0f - std::sqrt(c.d2) / r;

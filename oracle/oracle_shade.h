@@ -86,7 +86,7 @@ struct PhotonMap {
     std::vector<rtx_photon> ph;
     // uniform grid for neighbour queries
     float cell = 0;
-    V3 gmin;
+    int imin[3] = {0, 0, 0};
     int gx = 0, gy = 0, gz = 0;
     std::vector<int> cellStart, order;
     void scale(float s);

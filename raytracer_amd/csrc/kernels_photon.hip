@@ -130,6 +130,18 @@ __global__ __launch_bounds__(TRAV_BLOCK) void photon_emit_kernel(DevScene scArg,
     atomicAdd(&counts[3], segments);
 }
 
+// Bounding box of the stored photons as order-preserving integers (float bits, sign folded): out = {min xyz, max xyz}
+__device__ __forceinline__ uint32_t float_order(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__global__ void photon_bbox_kernel(PhotonSet s, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.n) return;
+    const float4 p = s.raw[i].pos;
+    atomicMin(&out[0], float_order(p.x)); atomicMin(&out[1], float_order(p.y)); atomicMin(&out[2], float_order(p.z));
+    atomicMax(&out[3], float_order(p.x)); atomicMax(&out[4], float_order(p.y)); atomicMax(&out[5], float_order(p.z));
+}
 __global__ void photon_count_kernel(PhotonSet s, uint32_t* __restrict__ cellCount) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= s.n) return;
@@ -157,6 +169,10 @@ void launch_photon_emit(const DevScene& sc, const LaunchCfg& cfg, int numPhotons
     else
         hipLaunchKernelGGL(photon_emit_kernel<false>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, numPhotons, first, stride, maxBounces,
                            seed, g, gcap, c, ccap, counts, cfg.spill);
+}
+void launch_photon_bbox(const PhotonSet& s, uint32_t* out6, hipStream_t st) {
+    if (!s.n) return;
+    hipLaunchKernelGGL(photon_bbox_kernel, dim3((s.n + 255) / 256), dim3(256), 0, st, s, out6);
 }
 void launch_photon_count(const PhotonSet& s, uint32_t* cellCount, hipStream_t st) {
     if (!s.n) return;

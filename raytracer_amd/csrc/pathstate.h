@@ -15,11 +15,11 @@
 #define RTX_SORT_KEY_BITS 18   // 3 octant bits above 15 Morton bits of a 32^3 origin cell
 
 struct DevPhotonMap {
-    const float4* pos;      // xyz, w unused          (sorted by cell)
+    const float4* pos;      // xyz, w = photon key    (sorted by cell, then key)
     const float4* dir;      // xyz
     const float4* power;    // rgb, already scaled
     const uint32_t* cellStart;  // gx*gy*gz + 1
-    float gmin[3];
+    int imin[3];            // the grid is the window [imin, imin + g) of the lattice floor(p / cell)
     float cell;
     int gx, gy, gz;
     int n;

@@ -23,7 +23,7 @@ struct PhotonSet {
     size_t cells = 0;
     int gx = 0, gy = 0, gz = 0;
     float cell = 0.0f;
-    float gmin[3] = {0, 0, 0};
+    int imin[3] = {0, 0, 0};       // first lattice cell of the grid window on each axis
     float radius = 0.0f;
 };
 

@@ -8,21 +8,21 @@
 #endif
 
 // ---- photon estimate ------------------------------------------------------------------------------------------
-// k nearest photons within `radius` via the uniform hash grid (cells of edge `radius`); see DESIGN.md for the
-// definition shared with the oracle. Two passes: (1) the k-th smallest squared distance by a bounded max-heap
-// kept in registers/scratch, (2) the cone-filtered sum over photons within it.
+// k nearest photons within `radius` via a uniform grid; see DESIGN.md for the definition shared with the oracle.
+// Two passes: (1) the k-th smallest (squared distance, photon key) by bisection on the 64-bit key, (2) the cone-filtered
+// sum over the photons up to it, in storage order = (cell, photon key) order. The oracle sums in the same order over the
+// same lattice (anchored at the origin, edge chosen from the photons' own bounding box), so estimates agree bit for bit.
 __device__ inline f3 estimate_irradiance(const DevPhotonMap& pm, f3 pos, f3 normal) {
     if (pm.n <= 0) return mk3(0.0f);
     const float radius = pm.radius;
     const float r2 = radius * radius;
     const int K = pm.maxPhotons;
-    int cx0 = (int)floorf((pos.x - radius - pm.gmin[0]) / pm.cell), cx1 = (int)floorf((pos.x + radius - pm.gmin[0]) / pm.cell);
-    int cy0 = (int)floorf((pos.y - radius - pm.gmin[1]) / pm.cell), cy1 = (int)floorf((pos.y + radius - pm.gmin[1]) / pm.cell);
-    int cz0 = (int)floorf((pos.z - radius - pm.gmin[2]) / pm.cell), cz1 = (int)floorf((pos.z + radius - pm.gmin[2]) / pm.cell);
-    // cell_of clamps photons into the border cells, so a query beyond the grid (photons handed in through
-    // rtx_photon_set need not lie inside the scene box) searches the border cells too; the distance test decides
-    cx0 = min(max(cx0, 0), pm.gx - 1); cy0 = min(max(cy0, 0), pm.gy - 1); cz0 = min(max(cz0, 0), pm.gz - 1);
-    cx1 = max(min(cx1, pm.gx - 1), 0); cy1 = max(min(cy1, pm.gy - 1), 0); cz1 = max(min(cz1, pm.gz - 1), 0);
+    // cells of the lattice floor(p / cell) that the search sphere's box touches, clamped to the grid window (in float, so
+    // that a far-away query cannot overflow the conversion); the distance test decides
+    const auto lc = [&](float x, int a, int g) { return (int)fminf(fmaxf(floorf(x / pm.cell) - (float)pm.imin[a], 0.0f), (float)(g - 1)); };
+    const int cx0 = lc(pos.x - radius, 0, pm.gx), cx1 = lc(pos.x + radius, 0, pm.gx);
+    const int cy0 = lc(pos.y - radius, 1, pm.gy), cy1 = lc(pos.y + radius, 1, pm.gy);
+    const int cz0 = lc(pos.z - radius, 2, pm.gz), cz1 = lc(pos.z + radius, 2, pm.gz);
     // pass 1: count candidates and find the K-th smallest (d2, index) by repeated threshold refinement:
     // a max-heap of K entries would need K registers; instead bisect on the key, which is exact because keys
     // are (d2 bits, index) pairs compared as 64-bit integers.
@@ -69,7 +69,7 @@ __device__ inline f3 estimate_irradiance(const DevPhotonMap& pm, f3 pos, f3 norm
     if (rr2 <= 0.0f) return mk3(0.0f);
     const float r = sqrtf(rr2);
     f3 irrad = mk3(0.0f);
-    // pass 2: accumulate in (d2, index) order is not reproducible on a grid walk; sum in grid order instead
+    // pass 2: the sum, in grid order
     for (int cz = cz0; cz <= cz1; ++cz)
         for (int cy = cy0; cy <= cy1; ++cy)
             for (int cx = cx0; cx <= cx1; ++cx) {

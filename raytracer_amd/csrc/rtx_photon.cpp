@@ -8,6 +8,7 @@
 
 void launch_photon_emit(const DevScene& sc, const LaunchCfg& cfg, int numPhotons, int first, int stride, int maxBounces,
                         unsigned long long seed, DevPhotonRec* g, uint32_t gcap, DevPhotonRec* c, uint32_t ccap, uint32_t* counts);
+void launch_photon_bbox(const PhotonSet& s, uint32_t* out6, hipStream_t st);
 void launch_photon_count(const PhotonSet& s, uint32_t* cellCount, hipStream_t st);
 int launch_photon_order(const PhotonSet& s, float scale, hipStream_t st);   // kernels_sort.hip
 void launch_photon_probe(const DevPhotonMap& pm, const float* pos, const float* nrm, uint32_t n, float* out, hipStream_t st);
@@ -20,7 +21,7 @@ void photon_device_map(const rtx_photons* p, int which, DevPhotonMap& out) {
     out.dir = s.dir;
     out.power = s.power;
     out.cellStart = s.cellStart;
-    std::memcpy(out.gmin, s.gmin, sizeof(out.gmin));
+    std::memcpy(out.imin, s.imin, sizeof(out.imin));
     out.cell = s.cell;
     out.gx = s.gx;
     out.gy = s.gy;
@@ -39,24 +40,48 @@ static void free_sorted(PhotonSet& s) {
     s.cellStart = nullptr;
 }
 
-// Scale powers, bin the photons into a uniform grid of cell edge >= radius over the scene box (cell counts + a radix
-// sort by (cell, photon key)).
+// Scale powers, bin the photons into a uniform grid (cell counts + a radix sort by (cell, photon key)).
 static int finalize_set(rtx_photons* p, int which, float scale) {
     PhotonSet& s = p->set[which];
     free_sorted(s);
     if (!s.n) return RTX_OK;
-    const float* b = p->scene->dev.bounds;
+    // The grid is a window of the lattice floor(p / cell) anchored at the origin. Its edge is the search radius doubled
+    // until the photons' own bounding box spans at most 512 cells per axis and 2^24 in all: a definition that depends on
+    // nothing but the photon records, which the oracle holds bit for bit, so both sides bin - and sum - alike.
+    uint32_t* dbox = nullptr;
+    uint32_t hbox[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    RTX_HIP(hipMalloc((void**)&dbox, sizeof(hbox)));
+    RTX_HIP(hipMemcpy(dbox, hbox, sizeof(hbox), hipMemcpyHostToDevice));
+    launch_photon_bbox(s, dbox, nullptr);
+    RTX_HIP(hipMemcpy(hbox, dbox, sizeof(hbox), hipMemcpyDeviceToHost));
+    (void)hipFree(dbox);
+    float lo[3], hi[3];
+    for (int a = 0; a < 6; ++a) {
+        const uint32_t u = (hbox[a] & 0x80000000u) ? (hbox[a] & 0x7FFFFFFFu) : ~hbox[a];
+        std::memcpy(a < 3 ? &lo[a] : &hi[a - 3], &u, 4);
+    }
     float cell = std::max(s.radius, 1e-6f);
-    float ext[3];
-    for (int a = 0; a < 3; ++a) {
-        s.gmin[a] = b[a] - 2.0f * s.radius;
-        ext[a] = (b[a + 3] + 2.0f * s.radius) - s.gmin[a];
-        cell = std::max(cell, ext[a] / 512.0f);
+    for (;; cell *= 2.0f) {
+        double total = 1.0;
+        bool ok = true;
+        for (int a = 0; a < 3; ++a) {
+            const float f0 = std::floor(lo[a] / cell), f1 = std::floor(hi[a] / cell);
+            const double d = (double)f1 - (double)f0 + 1.0;
+            if (!(d <= 512.0) || !(std::fabs(f0) < 4194304.0f) || !(std::fabs(f1) < 4194304.0f)) ok = false;
+            total *= d;
+        }
+        if (ok && total <= 16777216.0) break;
+        if (!(cell < 1e30f)) return rtx_fail(RTX_ERR_INVALID, "photon positions are not finite");
     }
     s.cell = cell;
-    s.gx = std::max(1, (int)(ext[0] / cell) + 1);
-    s.gy = std::max(1, (int)(ext[1] / cell) + 1);
-    s.gz = std::max(1, (int)(ext[2] / cell) + 1);
+    int g[3];
+    for (int a = 0; a < 3; ++a) {
+        s.imin[a] = (int)std::floor(lo[a] / cell);
+        g[a] = (int)std::floor(hi[a] / cell) - s.imin[a] + 1;
+    }
+    s.gx = g[0];
+    s.gy = g[1];
+    s.gz = g[2];
     s.cells = (size_t)s.gx * s.gy * s.gz;
     RTX_HIP(hipMalloc((void**)&s.pos, (size_t)s.n * sizeof(float4)));
     RTX_HIP(hipMalloc((void**)&s.dir, (size_t)s.n * sizeof(float4)));

@@ -7,6 +7,7 @@ import pytest
 
 from raytracer_amd import synth
 from raytracer_amd.scene import render_params
+from tests.helpers import assert_path_samples_identical
 from tests.oracle_ffi import OracleScene, OraclePhotons
 
 pytestmark = pytest.mark.gpu
@@ -22,43 +23,43 @@ def env(rtx):
 
 
 def _sorted(p):
-    k = np.lexsort((np.round(p["power"][:, 0], 3), np.round(p["pos"][:, 2], 3), np.round(p["pos"][:, 1], 3), np.round(p["pos"][:, 0], 3)))
+    """Records in a canonical order (the GPU stores them as its lanes finish, the oracle in emission order)."""
+    k = np.lexsort((p["power"][:, 0], p["dir"][:, 0], p["pos"][:, 2], p["pos"][:, 1], p["pos"][:, 0]))
     return p[k]
 
 
 def test_photon_sets_match(env):
+    """Both sides evaluate the same elementary functions (rtx_math.h), so every photon takes the same path: the stored
+    records are the same set, bit for bit (the GPU's are unscaled, the oracle's scaled by PhotonMapBuilder.cpp:38-50)."""
     sd, gs, osc, gp, op, N = env
     gi, oi = gp.info(), op.info()
-    assert gi["photon_radius"] == pytest.approx(oi["photon_radius"]) and gi["caustic_radius"] == pytest.approx(oi["caustic_radius"])
-    # stored-photon counts: identical up to a handful of photons whose Russian-roulette / lobe draw flips on fp noise
-    assert abs(gi["n_global"] - oi["n_global"]) <= max(3, 0.005 * oi["n_global"])
-    assert abs(gi["n_caustic"] - oi["n_caustic"]) <= max(3, 0.005 * oi["n_caustic"])
+    assert gi["photon_radius"] == oi["photon_radius"] and gi["caustic_radius"] == oi["caustic_radius"]
+    assert gi["n_global"] == oi["n_global"] and gi["n_caustic"] == oi["n_caustic"]
     assert oi["n_caustic"] > 100 and oi["n_global"] > 100
-    assert abs(gp.stats["rays_photon"] - oi["rays"]) <= 0.001 * oi["rays"]
+    assert gp.stats["rays_photon"] == oi["rays"]
     for which in (0, 1):
-        a, b = gp.download(which), op.download(which)          # GPU: unscaled raw records; oracle: scaled
-        scale = (1.0 / N) if which == 0 else 1.0 / max(1, len(b))
-        # total flux and centroid of the stored photons
-        assert np.allclose(a["power"].astype(np.float64).sum(0) * scale, b["power"].astype(np.float64).sum(0), rtol=2e-2)
-        assert np.allclose(a["pos"].mean(0), b["pos"].mean(0), atol=2e-2)
-        if len(a) == len(b):
-            sa, sb = _sorted(a), _sorted(b)
-            close = np.abs(sa["pos"] - sb["pos"]).max(1) < 1e-3
-            assert close.mean() > 0.98
+        a, b = _sorted(gp.download(which)), _sorted(op.download(which))
+        scale = np.float32(1.0) / np.float32(N if which == 0 else max(1, len(b)))
+        assert np.array_equal(a["pos"], b["pos"]) and np.array_equal(a["dir"], b["dir"])
+        assert np.array_equal(a["power"] * scale, b["power"])
 
 
 def test_irradiance_estimate(env):
+    """k nearest within the radius, cone filter: the lattice and the order of the sum are defined by the photon records
+    alone (DESIGN.md "Photon gather"), so the estimates are bit-identical."""
     sd, gs, osc, gp, op, N = env
+    rng = np.random.default_rng(5)
     for which in (0, 1):
         b = op.download(which)
         probe = (b["pos"][:: max(1, len(b) // 300)][:300] + np.float32(0.003)).astype(np.float32)
-        nrm = np.tile(np.array([[0, 1, 0]], np.float32), (len(probe), 1))
+        far = (probe[:20] + np.float32(50.0)).astype(np.float32)          # outside the grid window: nothing in reach
+        probe = np.concatenate([probe, far, b["pos"][:20].astype(np.float32)])   # ... and exactly on a photon
+        nrm = rng.normal(size=probe.shape).astype(np.float32)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
         ge, oe = gp.estimate(which, probe, nrm), op.estimate(which, probe, nrm)
-        assert np.isfinite(ge).all()
-        scale = np.abs(oe).max()
-        ok = np.abs(ge - oe).max(1) <= 0.02 * scale
-        assert ok.mean() >= 0.97
-        assert np.abs(ge - oe).mean() <= 0.005 * scale
+        assert np.isfinite(ge).all() and np.abs(oe).max() > 0
+        assert np.array_equal(ge.view(np.uint32), oe.view(np.uint32))
+        assert not ge[300:320].any()
 
 
 def test_caustic_term_in_path_loop(env):
@@ -67,8 +68,7 @@ def test_caustic_term_in_path_loop(env):
     rp = render_params(spp_min=4, max_bounces=4, use_photons=1)
     g, _ = gs.render_samples(cam, rp, gp)
     o = osc.render_samples(cam, rp, op)
-    d = np.abs(g[..., :3] - o[..., :3]).max(-1)
-    assert (d <= 1e-5 * (1 + np.abs(o[..., :3]).max(-1))).mean() >= 0.999
+    assert_path_samples_identical(g, o)
     base = osc.render_samples(cam, render_params(spp_min=4, max_bounces=4))
     assert np.abs(o[..., :3] - base[..., :3]).max() > 1e-4      # the caustic map does contribute
 
@@ -104,7 +104,7 @@ def test_photon_split_and_set(env, rtx):
     nrm = np.tile(np.array([[0, 1, 0]], np.float32), (len(probe), 1))
     for which in (0, 1):
         e1, e2 = a.estimate(which, probe, nrm), gp.estimate(which, probe, nrm)
-        assert np.allclose(e1, e2, rtol=1e-3, atol=1e-6 * max(1.0, np.abs(e2).max()))
+        assert np.array_equal(e1.view(np.uint32), e2.view(np.uint32))   # same records -> same (cell, key) order -> same bits
 
 
 def test_golden_photon_fixture(rtx):
@@ -113,8 +113,8 @@ def test_golden_photon_fixture(rtx):
     gs = rtx.Scene(sd)
     gp = rtx.Photons(gs, num_photons=100000)
     info = gp.info()
-    assert abs(info["n_global"] - int(g["n_global"])) <= 3 and abs(info["n_caustic"] - int(g["n_caustic"])) <= 3
-    assert np.allclose([info["photon_radius"], info["caustic_radius"]], g["info_radii"])
+    assert info["n_global"] == int(g["n_global"]) and info["n_caustic"] == int(g["n_caustic"])
+    assert np.array_equal(np.float32([info["photon_radius"], info["caustic_radius"]]), g["info_radii"])
     nn = np.tile(np.array([[0, 1, 0]], np.float32), (len(g["probe"]), 1))
     eg = gp.estimate(0, g["probe"], nn)
-    assert np.abs(eg - g["est_global"]).max() <= 0.02 * np.abs(g["est_global"]).max()
+    assert np.array_equal(eg.view(np.uint32), g["est_global"].view(np.uint32))
