@@ -206,7 +206,8 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_ray * agg["ext_rays"] / max(1, agg["launches"]),
                          "bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
                          "avg_launch_ms": agg["extend_ms"] / max(1, agg["launches"]), "launches": agg["launches"],
-                         "extend_Mrays_s": agg["ext_rays"] / max(1e-9, agg["extend_ms"]) / 1e3},
+                         "extend_Mrays_s": agg["ext_rays"] / max(1e-9, agg["extend_ms"]) / 1e3,
+                         "limiter": measured_limiter()},
             "kernel_ms_per_frame_rank0": {"extend": agg["extend_ms"] / a.steps, "shadow": agg["shadow_ms"] / a.steps,
                                           "shade": agg["shade_ms"] / a.steps},
         }
@@ -223,15 +224,27 @@ def measured_traffic(a, world):
     profiles/): 2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md "HBM") + WRITE_SIZE over the
     launches. A PMC run cannot be nested inside this process, so the figure is the committed measurement; it is
     reported only when this run is the configuration it was measured on."""
-    path = os.path.join(ROOT, "profiles", "r01", "extend_traffic_c3.json")
+    rel = next((r for r in ("profiles/r02/extend_traffic_c3.json", "profiles/r01/extend_traffic_c3.json") if os.path.exists(os.path.join(ROOT, r))), None)
+    path = os.path.join(ROOT, rel) if rel else ""
     default = (not a.legacy and a.tri_scale == 1.0 and a.width == 1920 and a.height == 1080 and a.spp == 128 and a.max_bounces == 64 and
                world == 1)
     if not default or not os.path.exists(path):
         return None, None
-    k = json.load(open(path))["kernels"].get("extend_kernel<false>")
+    # the non-counting instantiation of the extend kernel (extend_kernel<false> in round 1, <false, XF> since)
+    k = next((v for n, v in json.load(open(path))["kernels"].items() if n.startswith("extend_kernel<false")), None)
     if not k or not k["dispatches"]:
         return None, None
-    return (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 / k["dispatches"], "profiles/r01/extend_traffic_c3.json"
+    return (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 / k["dispatches"], rel
+
+
+def measured_limiter():
+    """What the PMC passes say holds the extend kernel back (committed measurement, not collected by this run)."""
+    path = os.path.join(ROOT, "profiles", "r02", "extend_limiter.json")
+    if not os.path.exists(path):
+        return None
+    j = json.load(open(path))
+    return {"what": "divergence + memory latency", "valu_issue_frac": j["valu_issue_frac_of_wave_time"],
+            "active_lanes_per_valu": j["active_lanes_per_valu"], "wait_frac": j["wait_any_frac"], "l2_hit": j["l2_hit"], "source": j["source"]}
 
 
 def cpu_baseline(sd, cam, a):
