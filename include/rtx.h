@@ -390,7 +390,10 @@ int64_t rtx_photon_download(const rtx_photons* p, int which, rtx_photon* out, si
 
 /* Multi-GPU: replace the caustic/global photon set with the concatenation gathered from all ranks (device
  * pointer to n raw records) and rebuild the hash grid + power scaling (PhotonMapBuilder.cpp:38-50).
- * Raw record = 12 floats: {pos.xyz, bits(photonId*4+bounce)}, {dir.xyz, 0}, {unscaled power.rgb, 0}. */
+ * Raw record = 12 floats: {pos.xyz, bits(photonId*4+bounce)}, {dir.xyz, 0}, {unscaled power.rgb, 0}.
+ * The reference's map capacities apply (PhotonMapBuilder.cpp:27-28: total_emitted records in the global map,
+ * total_emitted / 10 in the caustics map; a full map takes no more photons): beyond them the records with the smallest
+ * (photon, bounce) keys stay, here and in rtx_photon_build - the same map from one GPU or from many. */
 int rtx_photon_set(rtx_photons* p, int which, const void* photons_dev, size_t n, int total_emitted);
 
 /* Device address of the stored raw records (48 B each, layout above) for an RCCL all-gather by the caller. */

@@ -275,6 +275,11 @@ int orc_photon_build(void* s, const rtx_photon_params* pp, void** out) {
 // PhotonMapBuilder.cpp:38-50 scaling + PrepareForIrradianceEstimation
 int orc_photon_finalize(void* p, int total_emitted) {
     PhotonMapper* pm = (PhotonMapper*)p;
+    // PhotonMap::Resize(numPhotons) / Resize(numPhotons / 10), PhotonMapBuilder.cpp:27-28: a full map takes no more
+    // photons (cyPhotonMap absent: parity unpinned). Emission here runs in photon order, so the first ones stay.
+    const size_t capG = (size_t)std::max(0, total_emitted), capC = (size_t)(std::max(0, total_emitted) / 10);
+    if (pm->global.ph.size() > capG) pm->global.ph.resize(capG);
+    if (pm->caustic.ph.size() > capC) pm->caustic.ph.resize(capC);
     if (!pm->global.ph.empty()) {
         pm->global.scale(1.0f / float(total_emitted));
         pm->global.prepare(pm->photonRadius);

@@ -125,3 +125,66 @@ int launch_photon_order(const PhotonSet& s, float scale, hipStream_t st) {
     (void)hipFree(temp);
     return rc;
 }
+
+// ---- photon map capacity -----------------------------------------------------------------------------------------
+// PhotonMap::Resize(numPhotons) / Resize(numPhotons / 10) (PhotonMapBuilder.cpp:27-28): a full map takes no more
+// photons. Which ones the reference drops depends on its thread timing; here the records with the smallest
+// (photon, bounce) keys stay - what emission in photon order would have stored - so the result does not depend on the
+// order in which the emit kernel's lanes finished, nor on how many GPUs emitted.
+__global__ void photon_idkey_kernel(const DevPhotonRec* __restrict__ raw, uint32_t n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = __float_as_uint(raw[i].pos.w);
+    vals[i] = i;
+}
+__global__ void photon_pick_kernel(const DevPhotonRec* __restrict__ raw, const uint32_t* __restrict__ order, uint32_t keep,
+                                   DevPhotonRec* __restrict__ out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= keep) return;
+    out[k] = raw[order[k]];
+}
+// s.raw (s.n records) -> a new buffer of the `keep` records with the smallest keys; returns 0 or a hipError_t
+int launch_photon_keep_smallest(PhotonSet& s, uint32_t keep, hipStream_t st) {
+    if (keep >= s.n) return 0;
+    if (keep == 0) {
+        s.n = 0;
+        return 0;
+    }
+    uint32_t *keysIn = nullptr, *keysOut = nullptr, *valsIn = nullptr, *valsOut = nullptr;
+    DevPhotonRec* out = nullptr;
+    void* temp = nullptr;
+    size_t bytes = 0;
+    int rc = 0;
+    auto fail = [&](hipError_t e) { if (e != hipSuccess && !rc) rc = (int)e; return e != hipSuccess; };
+    if (fail(hipMalloc((void**)&keysIn, (size_t)s.n * 4)) || fail(hipMalloc((void**)&keysOut, (size_t)s.n * 4)) ||
+        fail(hipMalloc((void**)&valsIn, (size_t)s.n * 4)) || fail(hipMalloc((void**)&valsOut, (size_t)s.n * 4)) ||
+        fail(hipMalloc((void**)&out, (size_t)keep * sizeof(DevPhotonRec))) ||
+        fail(rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)keysIn, keysOut, (const uint32_t*)valsIn, valsOut, s.n, 0u, 32u, st)) ||
+        fail(hipMalloc(&temp, bytes ? bytes : 1))) {
+        (void)hipFree(out);
+        out = nullptr;
+    } else {
+        hipLaunchKernelGGL(photon_idkey_kernel, dim3((s.n + 255) / 256), dim3(256), 0, st, (const DevPhotonRec*)s.raw, s.n, keysIn, valsIn);
+        if (!fail(rocprim::radix_sort_pairs(temp, bytes, (const uint32_t*)keysIn, keysOut, (const uint32_t*)valsIn, valsOut, s.n, 0u, 32u, st))) {
+            hipLaunchKernelGGL(photon_pick_kernel, dim3((keep + 255) / 256), dim3(256), 0, st, (const DevPhotonRec*)s.raw, (const uint32_t*)valsOut,
+                               keep, out);
+            fail(hipStreamSynchronize(st));
+        }
+        if (rc) {
+            (void)hipFree(out);
+            out = nullptr;
+        }
+    }
+    (void)hipFree(keysIn);
+    (void)hipFree(keysOut);
+    (void)hipFree(valsIn);
+    (void)hipFree(valsOut);
+    (void)hipFree(temp);
+    if (out) {
+        (void)hipFree(s.raw);
+        s.raw = out;
+        s.n = keep;
+        s.capacity = keep;
+    }
+    return rc;
+}

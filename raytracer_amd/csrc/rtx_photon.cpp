@@ -11,6 +11,7 @@ void launch_photon_emit(const DevScene& sc, const LaunchCfg& cfg, int numPhotons
 void launch_photon_bbox(const PhotonSet& s, uint32_t* out6, hipStream_t st);
 void launch_photon_count(const PhotonSet& s, uint32_t* cellCount, hipStream_t st);
 int launch_photon_order(const PhotonSet& s, float scale, hipStream_t st);   // kernels_sort.hip
+int launch_photon_keep_smallest(PhotonSet& s, uint32_t keep, hipStream_t st);
 void launch_photon_probe(const DevPhotonMap& pm, const float* pos, const float* nrm, uint32_t n, float* out, hipStream_t st);
 
 void photon_device_map(const rtx_photons* p, int which, DevPhotonMap& out) {
@@ -29,6 +30,18 @@ void photon_device_map(const rtx_photons* p, int which, DevPhotonMap& out) {
     out.n = (int)s.n;
     out.radius = s.radius;
     out.maxPhotons = p->searchCount <= 30 ? 30 : (p->searchCount <= 50 ? 50 : 100);   // RayCaster.cpp:149-151
+}
+
+// Capacity of the reference's maps (PhotonMapBuilder.cpp:27-28): numPhotons for the global map, numPhotons / 10 for the
+// caustics map; a full map takes no more photons (cyPhotonMap is absent: parity unpinned)
+static uint32_t map_capacity(int which, int numPhotons) {
+    const int n = std::max(0, numPhotons);
+    return (uint32_t)(which == 0 ? n : n / 10);
+}
+static int clamp_to_capacity(rtx_photons* p, int which, int numPhotons) {
+    PhotonSet& s = p->set[which];
+    if (launch_photon_keep_smallest(s, map_capacity(which, numPhotons), nullptr) != 0) return rtx_fail(RTX_ERR_HIP, "photon map capacity clamp failed");
+    return RTX_OK;
 }
 
 static void free_sorted(PhotonSet& s) {
@@ -184,8 +197,11 @@ int rtx_photon_build(rtx_scene* s, const rtx_photon_params* pp, rtx_photons** ou
         stats->rays_photon = cnt[3];
         stats->total_ms = ms;
     }
+    // a strided share is clamped to the whole map's capacity too: what its own smallest keys do not hold, the union's cannot
+    rc = clamp_to_capacity(p, 0, pp->num_photons);
+    if (rc == RTX_OK) rc = clamp_to_capacity(p, 1, pp->num_photons);
     // PhotonMapBuilder.cpp:38-50: global map scaled by 1/emitted, caustic map by 1/stored
-    rc = finalize_set(p, 0, 1.0f / (float)std::max(1, pp->num_photons));
+    if (rc == RTX_OK) rc = finalize_set(p, 0, 1.0f / (float)std::max(1, pp->num_photons));
     if (rc == RTX_OK) rc = finalize_set(p, 1, p->set[1].n ? 1.0f / (float)p->set[1].n : 1.0f);
     if (rc != RTX_OK) {
         rtx_photons_destroy(p);
@@ -252,7 +268,9 @@ int rtx_photon_set(rtx_photons* p, int which, const void* photons_dev, size_t n,
     }
     if (n && photons_dev != s.raw) RTX_HIP(hipMemcpy(s.raw, photons_dev, n * sizeof(DevPhotonRec), hipMemcpyDeviceToDevice));
     s.n = (uint32_t)n;
-    const float scale = which == 0 ? 1.0f / (float)std::max(1, total_emitted) : (n ? 1.0f / (float)n : 1.0f);
+    const int rc = clamp_to_capacity(p, which, total_emitted);
+    if (rc != RTX_OK) return rc;
+    const float scale = which == 0 ? 1.0f / (float)std::max(1, total_emitted) : (s.n ? 1.0f / (float)s.n : 1.0f);
     return finalize_set(p, which, scale);
 }
 

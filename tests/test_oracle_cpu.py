@@ -399,3 +399,20 @@ def test_fuzz_generator_is_deterministic():
         assert [vars(m) for m in a.materials] == [vars(m) for m in b.materials]
     sd, cam, _ = rand_scene(39)                                        # the seed that found the mirrored-transform defect
     assert any(np.linalg.det(m.xform.reshape(3, 4)[:, :3]) < 0 for m in sd.meshes if m.kind == _ffi.OBJ_MESH)
+
+
+def test_photon_map_capacity():
+    """PhotonMapBuilder.cpp:27-28: the caustics map holds numPhotons / 10 records, the global map numPhotons; a full map
+    takes no more (stand-in for the absent cyPhotonMap): the records emitted first stay, and the caustic scale is
+    1 / (records kept)."""
+    from tests.oracle_ffi import OraclePhotons, OracleScene
+    from tests.test_photon_gpu import _glass_over_floor
+    osc = OracleScene(_glass_over_floor())
+    N = 20000
+    raw = OraclePhotons(osc, N, finalize=False)
+    full = raw.download(1)
+    assert len(full) > N // 10
+    kept = OraclePhotons(osc, N).download(1)
+    assert len(kept) == N // 10
+    assert np.array_equal(kept["pos"], full["pos"][:N // 10])
+    assert np.array_equal(kept["power"], full["power"][:N // 10] * (np.float32(1.0) / np.float32(N // 10)))

@@ -118,3 +118,58 @@ def test_golden_photon_fixture(rtx):
     nn = np.tile(np.array([[0, 1, 0]], np.float32), (len(g["probe"]), 1))
     eg = gp.estimate(0, g["probe"], nn)
     assert np.array_equal(eg.view(np.uint32), g["est_global"].view(np.uint32))
+
+
+def _glass_over_floor():
+    """A glass sheet (one interface) that covers a diffuse floor under one lamp: most stored photons are caustic photons."""
+    from raytracer_amd.scene import Light, Material, Mesh, SceneData
+    sd = SceneData()
+    sd.materials = [Material(diffuse=(0.7, 0.7, 0.7), specular=(0.1, 0.1, 0.1), glossiness=20.0),
+                    Material(diffuse=(0, 0, 0), specular=(0, 0, 0), refraction=(1.0, 1.0, 1.0), ior=1.5, glossiness=1e4)]
+    floor = np.array([[-3, 0, -3], [3, 0, -3], [3, 0, 3], [-3, 0, 3]], np.float32)
+    sheet = (floor * np.float32(0.9) + np.array([0, 0.6, 0], np.float32)).astype(np.float32)
+    up = np.array([0, 6.0, 0], np.float32)
+    # the same pair mirrored above the lamp (a diffuse ceiling behind a second sheet): photons that leave upwards count too
+    sd.meshes = [Mesh(floor, [[0, 2, 1], [0, 3, 2]], material=0), Mesh(sheet, [[0, 2, 1], [0, 3, 2]], material=1),
+                 Mesh((floor + up).astype(np.float32), [[0, 1, 2], [0, 2, 3]], material=0),
+                 Mesh((sheet * np.array([1, -1, 1], np.float32) + up).astype(np.float32), [[0, 1, 2], [0, 2, 3]], material=1)]
+    sd.lights = [Light((0.2, 3.0, -0.1), (30.0, 30.0, 28.0), size=0.2)]
+    return sd
+
+
+def test_map_capacity(rtx):
+    """PhotonMap::Resize(numPhotons) / Resize(numPhotons / 10) (PhotonMapBuilder.cpp:27-28): a full map takes no more
+    photons. Stand-in for the absent cyPhotonMap (parity unpinned): the smallest (photon, bounce) keys stay - on one GPU,
+    in the oracle, and when the map is put together from two strided halves."""
+    import torch
+    sd = _glass_over_floor()
+    gs, osc = rtx.Scene(sd), OracleScene(sd)
+    N = 20000
+    free = OraclePhotons(osc, N, finalize=False).info()          # what emission stores before any limit
+    assert free["n_caustic"] > N // 10, "the scene must overflow the caustics map"
+    gp, op = rtx.Photons(gs, num_photons=N), OraclePhotons(osc, N)
+    gi, oi = gp.info(), op.info()
+    assert oi["n_caustic"] == N // 10 and gi["n_caustic"] == N // 10
+    assert gi["n_global"] == oi["n_global"] <= N
+    a, b = _sorted(gp.download(1)), _sorted(op.download(1))
+    assert np.array_equal(a["pos"], b["pos"]) and np.array_equal(a["power"] * (np.float32(1.0) / np.float32(N // 10)), b["power"])
+    probe = b["pos"][:200].astype(np.float32)
+    nrm = np.tile(np.array([[0, 1, 0]], np.float32), (len(probe), 1))
+    e_full = gp.estimate(1, probe, nrm)
+    assert np.array_equal(e_full.view(np.uint32), op.estimate(1, probe, nrm).view(np.uint32)) and np.abs(e_full).max() > 0
+    # two strided halves, gathered and installed with rtx_photon_set: the same map
+    ha = rtx.Photons(gs, num_photons=N, first_photon=0, photon_stride=2)
+    hb = rtx.Photons(gs, num_photons=N, first_photon=1, photon_stride=2)
+    na, nb = ha.info()["n_caustic"], hb.info()["n_caustic"]
+    assert na + nb > N // 10
+    buf = torch.empty((na + nb, 12), dtype=torch.float32, device="cuda:0")
+    assert ha.copy_raw(1, buf.data_ptr(), na) == na and hb.copy_raw(1, buf[na:].data_ptr(), nb) == nb
+    torch.cuda.synchronize()
+    ha.set_raw(1, buf.data_ptr(), na + nb, N)
+    assert ha.info()["n_caustic"] == N // 10
+    assert np.array_equal(ha.estimate(1, probe, nrm).view(np.uint32), e_full.view(np.uint32))
+    # renders with the clamped map agree as well
+    from raytracer_amd.scene import make_camera
+    cam = make_camera((0.5, 2.0, 5.0), (0, 0.3, 0), fov=40, focaldist=5.0, dof=0.0, width=48, height=27)
+    rp = render_params(spp_min=4, max_bounces=4, use_photons=1)
+    assert_path_samples_identical(gs.render_samples(cam, rp, gp)[0], osc.render_samples(cam, rp, op))
