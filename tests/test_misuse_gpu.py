@@ -224,7 +224,8 @@ def test_photons_outside_the_scene_box(scene, rtx):
     rec[:, 4:7] = (0, -1, 0)
     rec[:, 8:11] = rng.uniform(0.5, 2.0, (n, 3)).astype(np.float32)
     buf = torch.from_numpy(rec).to("cuda:0")
-    assert gs.lib.rtx_photon_set(gp.h, 1, buf.data_ptr(), n, n) == 0
+    # total_emitted = 10 n: the caustics map holds total_emitted / 10 records (PhotonMapBuilder.cpp:28)
+    assert gs.lib.rtx_photon_set(gp.h, 1, buf.data_ptr(), n, 10 * n) == 0
     q = np.stack([centre, centre + np.float32(0.3), np.array([0, 0.5, 0], np.float32)])
     nrm = np.tile(np.array([[0, 1, 0]], np.float32), (len(q), 1))
     got = gp.estimate(1, q, nrm)
