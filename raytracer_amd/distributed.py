@@ -5,9 +5,19 @@ sample counts, min of z). Ranks do the same across GPUs with torch.distributed (
 ROCm; "gloo" in the CPU tests). Samples splat into neighbouring pixels (tent radius 1, RayCaster.cpp:810-829), so the
 exchange must be a sum-reduce of full-frame films, not a gather of disjoint tiles.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
+
+
+def _alone(group):
+    """No exchange needed: no process group, or a group of one. RTX_AMD_DIST_FORCE=1 runs the collectives of a
+    one-rank group anyway (the RCCL code path on a box with a single GPU: tests/test_multirank_gpu.py)."""
+    if not dist.is_initialized():
+        return True
+    return dist.get_world_size(group) == 1 and not os.environ.get("RTX_AMD_DIST_FORCE")
 
 
 def _staged(t, group):
@@ -24,7 +34,7 @@ def reduce_film(accum, count, z, dst=0, group=None, albedo=None, normal=None):
     current stream, and the next consumer of these buffers is librtx_amd (rtx_film_clear / rtx_film_resolve of the next
     step), which runs on the null stream of its own HIP runtime and has no stream ordering with torch. Without the
     synchronisation below the next step's clear could zero the film while the reduce still reads or writes it."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if _alone(group):
         return
     jobs = [(accum, dist.ReduceOp.SUM), (count, dist.ReduceOp.SUM), (z, dist.ReduceOp.MIN)]
     jobs += [(t, dist.ReduceOp.SUM) for t in (albedo, normal) if t is not None]
@@ -78,7 +88,7 @@ def all_gather_photons(photons, group=None, device=None):
     (PhotonMapBuilder.cpp:102-146, :38-50): the raw 48-B records of both sets are all-gathered (RCCL over xGMI; gloo
     stages through the host) and rtx_photon_set rebuilds the hash grid and the power scaling (global map: 1/emitted,
     caustic map: 1/stored over ALL ranks) on every rank. Returns (n_global, n_caustic) of the gathered map."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if _alone(group):
         info = photons.info()
         return info["n_global"], info["n_caustic"]
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())

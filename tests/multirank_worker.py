@@ -77,14 +77,15 @@ if __name__ == "__main__":
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = port
     local = rank if backend == "nccl" else 0
-    if world > 1:
+    force = bool(os.environ.get("RTX_AMD_DIST_FORCE"))   # a one-rank group whose collectives run all the same
+    if world > 1 or force:
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     res = run(rank, world, local)
-    np.savez(os.path.join(outdir, f"rank{rank}_of{world}.npz"), **res)
-    if world > 1:
+    np.savez(os.path.join(outdir, f"rank{rank}_of{world}{'_forced' if force else ''}.npz"), **res)
+    if world > 1 or force:
         dist.barrier()
         dist.destroy_process_group()

@@ -63,6 +63,26 @@ def test_all_gathered_photon_map_equals_single_rank_map(runs):
         assert np.array_equal(r["caustic_samples"].view(np.uint32), one["caustic_samples"].view(np.uint32))
 
 
+def test_rccl_code_path_with_one_rank(runs):
+    """The box has one GPU, and RCCL refuses two ranks on one device: so the nccl branches of reduce_film and
+    all_gather_photons (collectives on device tensors, all_gather_into_tensor, the host synchronisation against the
+    library's own HIP runtime) run here in a group of ONE rank whose collectives are forced, and must change nothing."""
+    one, _ = runs
+    env = dict(os.environ, RTX_TEST_BACKEND="nccl", RTX_AMD_DIST_FORCE="1")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    with tempfile.TemporaryDirectory() as tmp:
+        p = subprocess.run([sys.executable, os.path.join(HERE, "multirank_worker.py"), "0", "1", port, tmp], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=280)
+        assert p.returncode == 0, p.stdout[-3000:]
+        got = dict(np.load(os.path.join(tmp, "rank0_of1_forced.npz")))
+    for k in ("count0", "z0", "albedo2", "normal2", "probes", "total", "est0", "est1", "caustic_samples"):
+        assert np.array_equal(got[k], one[k]), k
+    assert np.allclose(got["accum1"], one["accum1"], rtol=1e-4, atol=1e-5)
+
+
 # ---- several members in ONE process (rtx_group: the C++ host's multi-GPU path) ----------------------------------
 # The test box has one GPU: members share it (device ids repeat), which exercises everything but the peer copies
 # themselves (a member on the root's device is merged in place).
