@@ -337,6 +337,18 @@ struct Emitter {
             *ebytes[a] = (uint8_t)E;
         }
         for (int i = 0; i < 4; ++i) nd.child[i] = refs[i];
+        // pad[0] bit i: child i's subtree holds a surface that lets light through (shadow_kernel follows only those once
+        // it knows an opaque blocker); pad[1]: any of them
+        for (int i = 0; i < nc; ++i) {
+            bool trans = false;
+            if (refs[i] & RTX_LEAF_FLAG) {
+                const uint32_t first = (refs[i] & 0x7FFFFFFFu) >> 3, cnt = (refs[i] & 7u) + 1u;
+                for (uint32_t k = 0; k < cnt; ++k) trans = trans || (out.tris[first + k].obj & TRI_OPAQUE) == 0u;
+            } else
+                trans = out.nodes[refs[i]].pad[1] != 0u;
+            if (trans) nd.pad[0] |= 1u << i;
+        }
+        nd.pad[1] = nd.pad[0] != 0u ? 1u : 0u;
         out.nodes[my] = nd;
         return my;
     }
@@ -421,6 +433,8 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
                 wb.add(w);
             }
             rootBox.add(wb);
+            const float ob[6] = {-1.0f, -1.0f, md.kind == RTX_OBJ_PLANE ? 0.0f : -1.0f, 1.0f, 1.0f, md.kind == RTX_OBJ_PLANE ? 0.0f : 1.0f};
+            std::memcpy(out.objXf[m].box, ob, sizeof(ob));
             SrcTri& t = src[(size_t)faceBase[m]];
             t.obj = m;
             t.face = 0;
@@ -439,6 +453,8 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
         // object box in local coordinates, then its 8 corners in root coordinates (Node::GetChildBoundBox)
         AABB local;
         for (int k = 0; k < md.nv; ++k) local.add(md.v + 3 * (size_t)k);
+        std::memcpy(out.objXf[m].box, local.lo, 12);       // TriObj's box: every vertex (cyTriMesh::ComputeBoundingBox)
+        std::memcpy(out.objXf[m].box + 3, local.hi, 12);
         if (md.nv > 0) {
             if (ident) rootBox.add(local);
             else
@@ -545,6 +561,11 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
         err = E.err;
         return false;
     }
+    // the references of children whose subtree holds a surface that lets light through carry RTX_REF_TRANS (bit 30: free
+    // below 2^27 triangles and nodes), so that the traversal's stack entries carry it too (traverse.h)
+    for (Node4& n : out.nodes)
+        for (int i = 0; i < 4; ++i)
+            if (n.child[i] != RTX_EMPTY_CHILD && ((n.pad[0] >> i) & 1u)) n.child[i] |= 0x40000000u;
     return true;
 }
 
@@ -556,6 +577,7 @@ struct Validator {
     // returns the exact box of the subtree
     AABB walk(uint32_t ref) {
         AABB b;
+        ref &= ~0x40000000u;   // RTX_REF_TRANS
         if (ref & RTX_LEAF_FLAG) {
             uint32_t first = (ref & 0x7FFFFFFFu) >> 3, cnt = (ref & 7u) + 1;
             for (uint32_t i = first; i < first + cnt; ++i) {

@@ -206,6 +206,13 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
     f3 o = mk3(0.0f), d = mk3(0.0f);
     float maxDist = 0.0f, visibility = 1.0f;
     int hop = 0;
+    // Early end of a hop, made exact: once an opaque blocker in front of the segment's end and of the lights is known, the
+    // hop's answer is 0 unless a surface that lets light through is hit before it (the chain would then restart from an
+    // offset origin - 1e-4 along that surface's normal, sideways to the ray - and may slip past the blocker's edge, or
+    // past the blocker itself when the two are closer than the offset). So the traversal goes on, but only into subtrees
+    // that hold such surfaces (mode 1: whole opaque subtrees are dropped unfetched); if one is hit in front of the
+    // blocker, the hop is traced again as a plain closest hit (mode 2). Visible() is then the reference's bit for bit.
+    int mode = 0;   // 0: looking for the first decisive blocker, 1: blocker known, 2: plain closest hit, 3: about to start 2
     for (;;) {
         // hops that reached their end are resolved in batches (see extend_kernel): the chain either ends or starts
         // its next hop in the same lane
@@ -214,14 +221,20 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
         const unsigned long long freeMask = finMask | __ballot(!active);
         if (finMask != 0ull && ((uint32_t)__popcll(freeMask) >= SHADOW_REFILL_MIN || freeMask == ~0ull)) {
             if (fin) {
-                intersect_lights(sc, s.r, s.best);
-                float T;
-                if (shadow_hop_end(sc, o, d, maxDist, s.best, (useTransmittance & 1) != 0, hop, visibility, T)) {
-                    pool.nee[(size_t)(code & 7u) * pool.capacity + (code >> 3)].w = T;
-                    active = false;
-                } else {
+                bool next = true;
+                if (mode != 3) {
+                    intersect_lights(sc, s.r, s.best);
+                    float T;
+                    if (shadow_hop_end(sc, o, d, maxDist, s.best, (useTransmittance & 1) != 0, hop, visibility, T)) {
+                        pool.nee[(size_t)(code & 7u) * pool.capacity + (code >> 3)].w = T;
+                        active = false;
+                        next = false;
+                    } else
+                        hops++;
+                }
+                if (next) {   // the next hop, or the same hop again as a plain closest hit (mode 3 -> 2)
                     trav_init(s, sc, RayT{o.x, o.y, o.z, d.x, d.y, d.z, maxDist});
-                    hops++;
+                    mode = mode == 3 ? 2 : 0;
                 }
             }
         }
@@ -243,6 +256,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
                     visibility = 1.0f;
                     hop = 0;
                     trav_init(s, sc, RayT{o.x, o.y, o.z, d.x, d.y, d.z, maxDist});
+                    mode = 0;
                     hops++;
                     active = true;
                 }
@@ -261,17 +275,38 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
 #if SHADOW_ANYHIT
                     const int before = s.best.slot;
                     trav_leaf_test(s, sc, s.cur, RTX_HIT_FRONT_AND_BACK);
-                    if (s.best.slot != before && (useTransmittance & 2) == 0 && shadow_hit_decides(sc, s, maxDist, (useTransmittance & 1) != 0)) {
-                        s.cur = RTX_TRAV_DONE;   // the chain ends with 0 at this blocker (shadow_hop_end)
+                    bool stop = false;   // the hop ends here: decided (VisibleSimple), or to be traced again
+                    if (s.best.slot != before && (useTransmittance & 2) == 0 && mode != 2) {
+                        const bool withT = (useTransmittance & 1) != 0;
+                        if (mode == 1) {
+                            // a closer hit: another opaque surface changes nothing, one that lets light through ends the shortcut
+                            if ((sc.tris[s.best.slot].obj & TRI_OPAQUE) == 0u) {
+                                mode = 3;
+                                stop = true;
+                            }
+                        } else if (shadow_hit_decides(sc, s, maxDist, withT)) {
+                            if (withT) mode = 1;
+                            else stop = true;   // VisibleSimple: whatever the closest hit is, it lies in front of this one and blocks
+                        }
+                    }
+                    if (stop) {
+                        s.cur = RTX_TRAV_DONE;
                         s.sp = 0;
+                    } else if (mode == 1) {   // blocker known: only subtrees with surfaces that let light through
+                        s.cur = 0u;           // (an untagged reference: the leaf just tested is done with)
+                        trav_skip_opaque(s, st);
                     } else
                         trav_pop(s, st);
 #else
                     trav_leaf_step(s, sc, st, RTX_HIT_FRONT_AND_BACK);
 #endif
                 }
-            } else if (atInner)
+            } else if (atInner) {
                 trav_inner_step(s, sc, st);
+#if SHADOW_ANYHIT
+                if (mode == 1) trav_skip_opaque(s, st);
+#endif
+            }
         }
     }
     atomicAdd(&pool.rayCounters[0], (unsigned long long)hops);

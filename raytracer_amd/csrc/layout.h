@@ -27,14 +27,15 @@
 #define STACK_GLOBAL (128 - STACK_LDS)
 #define TRAV_BLOCK 256
 
-// child reference: inner node -> node index; leaf -> LEAF_FLAG | (firstTri << 3) | (count - 1)
+// child reference: inner node -> node index; leaf -> LEAF_FLAG | (firstTri << 3) | (count - 1); either one | RTX_REF_TRANS (bit 30,
+// traverse.h) when the subtree holds a surface that lets light through
 struct Node4 {
     float ox, oy, oz;       // quantisation origin = node box min
     uint8_t ex, ey, ez, nchild;  // biased fp32 exponents of the per-axis scale (scale = 2^(e-127))
     uint32_t child[4];
     uint8_t qlo[3][4];      // [axis][child], box lo = o + q * scale (rounded down)
     uint8_t qhi[3][4];      // box hi (rounded up)
-    uint32_t pad[2];
+    uint32_t pad[2];        // [0] bit i: child i's subtree holds a surface that lets light through (no TRI_OPAQUE); [1]: any child does
 };
 static_assert(sizeof(Node4) == 64, "Node4 must be 64 bytes");
 
@@ -77,6 +78,8 @@ struct ObjRec {
 struct ObjXform {
     float fwd[12];          // object -> world, 3x4 row-major
     float inv[12];          // world -> object
+    float box[6];           // Object::GetBoundBox() in object coordinates: min xyz, max xyz (the box of IntersectNodeAdapter.h:63-75)
+    float pad[2];
 };
 
 struct DevTexMap {
@@ -122,6 +125,6 @@ struct DevScene {
     float env[3]; int env_tex;
     float bg[3];  int bg_tex;
     float bg_emission;
-    int has_xf;             // some mesh sits under a non-identity node transform (RTX_KIND_XFTRI records): selects the kernel
+    int has_xf;             // some record is not a world-space triangle (a mesh under a non-identity node transform, a Sphere, a Plane): selects the kernel
                             // instantiations that carry the object-space triangle test (traverse.h DevSceneT)
 };

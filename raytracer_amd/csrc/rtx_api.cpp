@@ -128,7 +128,9 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     d.n_nodes = (int)hs.nodes.size();
     d.n_objs = (int)hs.objs.size();
     for (const ObjRec& o : hs.objs)
-        if (o.flags & OBJ_XFMESH) d.has_xf = 1;   // selects the kernels that carry the object-space triangle test
+        if (o.flags & OBJ_XFMESH) d.has_xf = 1;   // selects the kernels that carry the object-space triangle test ...
+    for (const TriRec& t : hs.tris)
+        if (t.kind != 0u) d.has_xf = 1;           // ... and the Sphere / Plane test (any record that is not a world-space triangle)
     std::memcpy(d.bounds, hs.bounds, sizeof(d.bounds));
     s->nTris = hs.tris.size();
     s->nNodes = hs.nodes.size();

@@ -81,11 +81,11 @@ __device__ __forceinline__ bool shadow_hop_end(const DevScene& sc, f3& o, f3 d, 
     return hop >= 8;   // kMaxHops with transmittance: the chain gives up with 0
 }
 
-// Early end of a shadow hop: the hit just accepted (s.best) already decides the whole chain when it is a blocker
-// that no later hop can get past - an opaque surface (any surface for VisibleSimple) in front of the segment's end
-// and of every renderable light. Closer hits can only be transmissive ones, whose hops continue towards the same
-// blocker (or give up with 0 themselves, :268-276), so Visible() returns 0 and the rest of the traversal is not
-// needed. The margins keep hits within rounding of the segment end or of a light surface on the full path.
+// Early end of a shadow hop: the hit just accepted (s.best) is a blocker that ends the chain with 0 if it turns out to be
+// the hop's closest hit - an opaque surface (any surface for VisibleSimple) in front of the segment's end and of every
+// renderable light. A closer OPAQUE hit gives 0 as well; a closer hit that lets light through does not (its next hop
+// starts from an offset origin and need not meet this blocker again), so the caller goes on looking for those alone
+// (shadow_kernel). The margins keep hits within rounding of the segment end or of a light surface on the full path.
 __device__ __forceinline__ bool shadow_hit_decides(const DevScene& sc, const TravState& s, float maxDist, bool useTransmittance) {
     if (s.best.slot < 0) return false;
     if (!(s.best.t < (maxDist - 1e-4f) * 0.99999f)) return false;

@@ -46,8 +46,41 @@ struct TravStack {
 
 __device__ __forceinline__ float scale_from_exp(uint32_t e) { return __uint_as_float(e << 23); }
 
+// Box::IntersectRay (scene_box.cpp:8-46) as written. The reference reaches an object's IntersectRay only through this test
+// on the object's own box, with the ray in node coordinates (IntersectNodeAdapter.h:63-75), and the whole scene through
+// the same test on the root's child box (:30-32). The test is exact arithmetic on an exact box, so a hit within rounding
+// of the box's silhouette - an edge of a Plane or of a box-shaped mesh, the rim of a floor quad - is culled or not by the
+// rounding of THESE operations. They are repeated here for Sphere and Plane (test_analytic: the flat box of a Plane makes
+// every one of its edges such a silhouette). For meshes they are NOT (DESIGN.md 4 "box culls"): the test would have to sit
+// where a triangle hit is accepted, or where a traversal ends, and either place costs the closest-hit kernels their
+// registers (extend_kernel +78 % / +34 %; even a one-register "skip this object" compare +18 %). box = {min xyz, max xyz}.
+__device__ __forceinline__ bool ref_box_hit(const float* box, float px, float py, float pz, float dx, float dy, float dz, float t_max) {
+#pragma clang fp contract(off)
+    const float p[3] = {px, py, pz}, d[3] = {dx, dy, dz};
+    float tmin = 0.0f, tmax = t_max;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float minv = box[i], maxv = box[3 + i];
+        if (fabsf(d[i]) < 1e-20f) {
+            if (p[i] < minv || p[i] > maxv) return false;
+            continue;
+        }
+        const float invD = 1.0f / d[i];
+        float t0 = (minv - p[i]) * invD, t1 = (maxv - p[i]) * invD;
+        if (t0 > t1) {
+            const float tt = t0;
+            t0 = t1;
+            t1 = tt;
+        }
+        if (t0 > tmin) tmin = t0;
+        if (t1 < tmax) tmax = t1;
+        if (tmax < tmin) return false;
+    }
+    return tmax >= 0.0f && tmin <= t_max;
+}
+
 // One triangle, objects.cpp:140-171 and :190-191. The arithmetic order is the reference's; contraction is off so
-// that u, v and t are bit-identical to an fp32 CPU evaluation.
+// that u, v and t are bit-identical to an fp32 CPU evaluation. r is the ray in the triangle's own space.
 __device__ __forceinline__ void test_triangle(const float4 a, const float4 b, const float4 c, const RayT& r, int hitSide,
                                               uint32_t slot, const TriRec* tris, HitT& best, uint32_t& bestPrim) {
 #pragma clang fp contract(off)
@@ -113,6 +146,7 @@ __device__ __forceinline__ void test_analytic(const DevScene& sc, uint32_t kind,
 #pragma clang fp contract(off)
     float p[3], d[3];
     ray_to_object(sc, obj, r, p, d);
+    if (!ref_box_hit(sc.objXf[obj].box, p[0], p[1], p[2], d[0], d[1], d[2], best.t)) return;   // [-1,1]^3, or the flat [-1,1]^2 x {0}
     float t;
     bool front;
     if (kind == RTX_OBJ_SPHERE) {
@@ -157,6 +191,8 @@ __device__ __forceinline__ void test_analytic(const DevScene& sc, uint32_t kind,
 // a ray transform; merely compiling it into the traversal loop raises its register pressure (28 spilled VGPRs, extend
 // +68 % on scenes that hold no such mesh - every object of cerealBar.xml is an identity node), and as a non-inlined
 // call it costs more still. So the kernels exist in two instantiations and the launch wrappers pick by DevScene::has_xf.
+// The Sphere / Plane test rides in the same instantiation (with its reference box test it costs the lean kernel 18 %):
+// kXF = false is a scene of world-space triangles and nothing else - every object of cerealBar.xml.
 template <bool XF>
 struct DevSceneT : DevScene {
     static constexpr bool kXF = XF;
@@ -167,7 +203,8 @@ __device__ __forceinline__ void test_primitive(const SC& sc, const float4 a, con
                                                int hitSide, uint32_t slot, HitT& best, uint32_t& bestPrim) {
     const uint32_t kind = __float_as_uint(b.w);
     if (kind == 0u) test_triangle(a, b, c, r, hitSide, slot, sc.tris, best, bestPrim);
-    else if (SC::kXF && kind == RTX_KIND_XFTRI) {
+    else if (!SC::kXF) return;   // identity meshes only (DevScene::has_xf == 0): no other kind of record exists
+    else if (kind == RTX_KIND_XFTRI) {
         // a mesh under a non-identity node transform: the ray goes to node coordinates (direction not renormalised, so t
         // is the same parameter) and meets the object's own fp32 vertices (IntersectNodeAdapter.h:62 -> objects.cpp:140)
         float p[3], d[3];
@@ -230,6 +267,23 @@ __device__ __forceinline__ void trav_pop(TravState& s, TravStack& st) {
     }
     s.cur = next;
 }
+// Child references carry RTX_REF_TRANS when the subtree holds a surface that lets light through (set by the builder), and so
+// do s.cur and the stack entries; the bit is masked where a node is addressed and where a leaf reference is decoded.
+// trav_skip_opaque drops everything that does not carry it, without a fetch: what is left of a shadow hop once its
+// blocker is known (shadow_kernel).
+#define RTX_REF_TRANS 0x40000000u   // free in every reference: fewer than 2^27 triangles and nodes (bvh_build.cpp)
+__device__ __forceinline__ void trav_skip_opaque(TravState& s, TravStack& st) {
+    if (s.cur == RTX_TRAV_DONE || (s.cur & RTX_REF_TRANS) != 0u) return;
+    uint32_t next = RTX_TRAV_DONE;
+    while (s.sp > 0) {
+        const uint2 e = st.pop(s.sp);
+        if ((e.x & RTX_REF_TRANS) != 0u && __uint_as_float(e.y) <= s.best.t * RTX_CULL_SLACK) {
+            next = e.x;
+            break;
+        }
+    }
+    s.cur = next;
+}
 
 // One inner node (64 B = 4 x dwordx4). The slab test runs in the node's quantised frame: with scale = 2^e exact,
 // t = (q - (ro - o)/scale) * (scale/dir), and the near/far planes of an axis go through one packed subtract and one
@@ -243,10 +297,11 @@ __device__ __forceinline__ void trav_pop(TravState& s, TravStack& st) {
 typedef float rtx_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void trav_inner_step(TravState& s, const DevScene& sc, TravStack& st) {
     const uint4* nodes4 = reinterpret_cast<const uint4*>(sc.nodes);
-    const uint4 w0 = nodes4[(size_t)s.cur * 4 + 0];  // ox oy oz | ex ey ez n
-    const uint4 w1 = nodes4[(size_t)s.cur * 4 + 1];  // child[4]
-    const uint4 w2 = nodes4[(size_t)s.cur * 4 + 2];  // qlo x[4] y[4] z[4] | qhi x[4]
-    const uint4 w3 = nodes4[(size_t)s.cur * 4 + 3];  // qhi y[4] z[4] | pad
+    const size_t node = (size_t)(s.cur & ~RTX_REF_TRANS);
+    const uint4 w0 = nodes4[node * 4 + 0];  // ox oy oz | ex ey ez n
+    const uint4 w1 = nodes4[node * 4 + 1];  // child[4]
+    const uint4 w2 = nodes4[node * 4 + 2];  // qlo x[4] y[4] z[4] | qhi x[4]
+    const uint4 w3 = nodes4[node * 4 + 3];  // qhi y[4] z[4] | pad
     const uint32_t ex = w0.w & 0xFFu, ey = (w0.w >> 8) & 0xFFu, ez = (w0.w >> 16) & 0xFFu;
     // direction reciprocal per quantised unit and ray origin in quantised units (exact power-of-two scalings)
     const float qdx = s.idx * scale_from_exp(ex), qdy = s.idy * scale_from_exp(ey), qdz = s.idz * scale_from_exp(ez);
@@ -311,7 +366,7 @@ __device__ __forceinline__ void trav_inner_step(TravState& s, const DevScene& sc
 template <class SC>
 __device__ __forceinline__ uint32_t trav_leaf_test(TravState& s, const SC& sc, uint32_t ref, int hitSide) {
     const float4* tris4 = reinterpret_cast<const float4*>(sc.tris);
-    const uint32_t first = (ref & 0x7FFFFFFFu) >> 3;
+    const uint32_t first = (ref & 0x3FFFFFFFu) >> 3;   // without the leaf flag and RTX_REF_TRANS (shadow tree)
     const uint32_t cnt = (ref & 7u) + 1u;
     for (uint32_t k = 0; k < cnt; ++k) {
         const uint32_t slot = first + k;

@@ -172,7 +172,7 @@ def test_scheduling_switches_do_not_change_results(small, monkeypatch):
     full, st1 = gs.render_samples(cam, rp)
     monkeypatch.delenv("RTX_AMD_SHADOW_EARLY_EXIT")
     assert np.array_equal(base, full)
-    assert st1["rays_shadow"] > st0["rays_shadow"]                  # the exit does save hops
+    assert st1["rays_shadow"] == st0["rays_shadow"]                 # the same chains hop for hop: the exit shortens traversals only
     monkeypatch.setenv("RTX_AMD_OVERLAP", "0")
     serial, _ = gs.render_samples(cam, rp)
     monkeypatch.delenv("RTX_AMD_OVERLAP")

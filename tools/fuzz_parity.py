@@ -204,6 +204,10 @@ def api_leg(gs, osc, sd, cam, rng, seed):
     ok_t = np.abs(g["t"][k] - o["t"][k]) <= 2e-5 * (1 + np.abs(o["t"][k]))
     ok_f = g["front"][k] == o["front"][k]
     ok_n = np.abs(g["N"][k] - o["N"][k]).max(-1) <= 1e-4 if k.any() else np.ones(0, bool)
+    if EXACT and not (same.all() and same_bits(g["t"][k], o["t"][k]) and (g["front"][k] == o["front"][k]).all() and
+                      same_bits(g["N"][k], o["N"][k]) and same_bits(g["p"][k], o["p"][k])):
+        msgs.append(f"closest side {side} lights {int(wl)}: not bit-identical (same {same.mean():.5f}, t {np.mean(g['t'][k] == o['t'][k]):.5f}, "
+                    f"N {np.mean((g['N'][k] == o['N'][k]).all(-1)):.5f}, p {np.mean((g['p'][k] == o['p'][k]).all(-1)):.5f})")
     if same.mean() < 0.995 or (k.any() and (ok_t.mean() < 0.999 or ok_f.mean() < 0.999 or ok_n.mean() < 0.995)):
         msgs.append(f"closest side {side} lights {int(wl)}: same {same.mean():.4f} t {ok_t.mean():.4f} front {ok_f.mean():.4f} N {ok_n.mean():.4f}")
     if os.environ.get("FUZZ_VERBOSE") and not same.all():
@@ -236,6 +240,8 @@ def api_leg(gs, osc, sd, cam, rng, seed):
     ut = bool(rng.random() < 0.7)
     gv, ov = gs.trace_visibility(seg, nrm, use_transmittance=ut), osc.trace_visibility(seg, nrm, use_transmittance=ut)
     okv = np.abs(gv - ov) <= 2e-3
+    if EXACT and not same_bits(gv, ov):
+        msgs.append(f"visibility transmittance {int(ut)}: {np.mean(gv == ov):.5f} bit-identical")
     if okv.mean() < 0.995:
         msgs.append(f"visibility transmittance {int(ut)}: {okv.mean():.4f}")
     ft = int(rng.integers(0, 4))
@@ -251,9 +257,19 @@ def api_leg(gs, osc, sd, cam, rng, seed):
         for y, x in list(zip(ys, xs))[:10]:
             print(f"      pixel ({x},{y}): samples {gi['samples'][y, x]}/{oi['samples'][y, x]} z {gi['z'][y, x]:.6f}/{oi['z'][y, x]:.6f} "
                   f"linear {gi['linear'][y, x]} / {oi['linear'][y, x]}")
+    if EXACT and (eq < 1.0 or not same_bits(gi["z"], oi["z"])):
+        msgs.append(f"adaptive render: sample maps equal {eq:.5f}, z bit-identical {np.mean(gi['z'] == oi['z']):.5f}")
     if eq < 0.97 or dl > 0.03 or dz < 0.99 or not np.isfinite(gi["linear"]).all():
         msgs.append(f"adaptive render filter {ft}/{rp.filter_radius:.1f} spp {rp.spp_min}..{rp.spp_max}: samples equal {eq:.4f} linear diff {dl:.4f} z {dz:.4f}")
     return msgs
+
+
+EXACT = False
+
+
+def same_bits(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return a.shape == b.shape and bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
 
 
 def agree(g, o, tol):
@@ -272,7 +288,11 @@ def main():
     ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--tol", type=float, default=2e-3)
     ap.add_argument("--min-agree", type=float, default=0.98)
+    ap.add_argument("--exact", action="store_true", help="round-2 bar: path-mode samples, primary distances, closest hits, visibility, photon "
+                    "counts and estimates bit-identical; legacy mode within 1e-5 on 99.99 %% of samples")
     a = ap.parse_args()
+    global EXACT
+    EXACT = a.exact
     lo, hi = (int(x) for x in a.seeds.split(":"))
     modes = {"path": [_ffi.SHADING_PATH], "legacy": [_ffi.SHADING_LEGACY], "both": [_ffi.SHADING_PATH, _ffi.SHADING_LEGACY]}[a.mode]
     worst, bad = 1.0, []
@@ -300,7 +320,7 @@ def main():
             gi, oi = gp.info(), op.info()
             msgs = []
             for k in ("n_global", "n_caustic"):
-                if abs(gi[k] - oi[k]) > max(3, 0.005 * oi[k]):
+                if abs(gi[k] - oi[k]) > (0 if EXACT else max(3, 0.005 * oi[k])):
                     msgs.append(f"{k} {gi[k]} / {oi[k]}")
             if abs(gi["photon_radius"] - oi["photon_radius"]) > 1e-6 or abs(gi["caustic_radius"] - oi["caustic_radius"]) > 1e-6:
                 msgs.append(f"radii {gi['photon_radius']},{gi['caustic_radius']} / {oi['photon_radius']},{oi['caustic_radius']}")
@@ -313,6 +333,8 @@ def main():
                 ge, oe = gp.estimate(which, sel["pos"], nn), op.estimate(which, sel["pos"], nn)
                 sc = np.abs(oe).max() + 1e-12
                 okp = (np.abs(ge - oe).max(-1) <= 0.03 * sc).mean()
+                if EXACT and not same_bits(ge, oe):
+                    msgs.append(f"estimate map {which}: {np.mean((ge == oe).all(-1)):.4f} of the probes bit-identical")
                 if okp < 0.95:
                     msgs.append(f"estimate map {which}: {okp:.3f} within 3 % of the largest ({len(sel)} probes of {len(ph)} photons)")
             for m in msgs:
@@ -342,10 +364,14 @@ def main():
             if sd.background_emission > 0.0:
                 need = min(need, 0.95)
             flag = "" if (ag >= need and dz.mean() >= 0.999 and (fin or not ofin)) else "   <-- CHECK"
+            ex = float(((g.view(np.uint32) == o.view(np.uint32)) | (np.isnan(g) & np.isnan(o))).all(-1).mean())
+            if EXACT:
+                ok = ex == 1.0 if mode == _ffi.SHADING_PATH else (agree(g, o, 1e-5) >= 0.9999 and same_bits(g[..., 3], o[..., 3]))
+                flag = "" if ok else "   <-- CHECK"
             if flag:
                 bad.append((seed, mode))
             print(f"seed {seed:4d} mode {mode} {cam.width:3d}x{cam.height:<3d} objs {len(sd.meshes):2d} tris {sd.n_triangles:4d} lights {len(sd.lights)} "
-                  f"bounces {rp.max_bounces:2d}  agree {ag:.4f}  z {dz.mean():.4f}  finite gpu/oracle {int(fin)}/{int(ofin)}  "
+                  f"bounces {rp.max_bounces:2d}  agree {ag:.4f}  exact {ex:.5f}  z {dz.mean():.4f}  finite gpu/oracle {int(fin)}/{int(ofin)}  "
                   f"mean {g[..., :3].mean():.4f}/{o[..., :3].mean():.4f}{flag}", flush=True)
     print(f"worst agreement {worst:.4f}; scenes to check: {bad}")
     return 1 if bad else 0
