@@ -706,6 +706,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene scArg, DevC
         if (!complete) continue;
         // ---- completion of a finished ray ----
         const bool isRoot = rootPending;
+        if (!isRoot && !trav_verify(ts, sc)) continue;   // general kernels: culled by its object's box in the reference, traced again without it
         const HitT h = isRoot ? rootH : ts.best;
         inFlight = false;
         rootPending = false;

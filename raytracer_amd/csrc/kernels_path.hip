@@ -220,7 +220,9 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
         const unsigned long long finMask = __ballot(fin);
         const unsigned long long freeMask = finMask | __ballot(!active);
         if (finMask != 0ull && ((uint32_t)__popcll(freeMask) >= SHADOW_REFILL_MIN || freeMask == ~0ull)) {
-            if (fin) {
+            if (fin && mode != 3 && !trav_verify(s, sc)) {
+                mode = 0;   // general kernels: the hop's hit is culled by its object's box in the reference, traced again without that object
+            } else if (fin) {
                 bool next = true;
                 if (mode != 3) {
                     intersect_lights(sc, s.r, s.best);

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(EXTE
         const unsigned long long finMask = __ballot(fin);
         const unsigned long long freeMask = finMask | __ballot(!active);
         if (finMask != 0ull && ((uint32_t)__popcll(freeMask) >= REFILL_MIN || freeMask == ~0ull)) {
-            if (fin) {
+            if (fin && trav_verify(s, sc)) {   // (general kernels: a hit the reference's box tests cull is traced again without that object)
                 if (withLights) intersect_lights(sc, s.r, s.best);
                 hits[rayIndex] = make_float4(s.best.t, s.best.u, s.best.v, __int_as_float(s.best.slot));
                 if (COUNT) rayCount++;

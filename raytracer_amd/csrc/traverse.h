@@ -50,10 +50,11 @@ __device__ __forceinline__ float scale_from_exp(uint32_t e) { return __uint_as_f
 // on the object's own box, with the ray in node coordinates (IntersectNodeAdapter.h:63-75), and the whole scene through
 // the same test on the root's child box (:30-32). The test is exact arithmetic on an exact box, so a hit within rounding
 // of the box's silhouette - an edge of a Plane or of a box-shaped mesh, the rim of a floor quad - is culled or not by the
-// rounding of THESE operations. They are repeated here for Sphere and Plane (test_analytic: the flat box of a Plane makes
-// every one of its edges such a silhouette). For meshes they are NOT (DESIGN.md 4 "box culls"): the test would have to sit
-// where a triangle hit is accepted, or where a traversal ends, and either place costs the closest-hit kernels their
-// registers (extend_kernel +78 % / +34 %; even a one-register "skip this object" compare +18 %). box = {min xyz, max xyz}.
+// rounding of THESE operations. They are repeated by the general kernels (SC::kXF: scenes that hold a mesh under a node
+// transform, a Sphere or a Plane): in test_analytic on the way in, and in trav_verify for the mesh hit a traversal ends
+// with. The lean kernels - scenes of world-space triangles only, every object of cerealBar.xml - do NOT repeat them
+// (DESIGN.md 4 "box culls"): wherever the test sits, it costs extend_kernel its registers (+78 % where a hit is
+// accepted, +34 % where a traversal ends; a one-register "skip this object" compare alone +18 %). box = {min xyz, max xyz}.
 __device__ __forceinline__ bool ref_box_hit(const float* box, float px, float py, float pz, float dx, float dy, float dz, float t_max) {
 #pragma clang fp contract(off)
     const float p[3] = {px, py, pz}, d[3] = {dx, dy, dz};
@@ -82,7 +83,8 @@ __device__ __forceinline__ bool ref_box_hit(const float* box, float px, float py
 // One triangle, objects.cpp:140-171 and :190-191. The arithmetic order is the reference's; contraction is off so
 // that u, v and t are bit-identical to an fp32 CPU evaluation. r is the ray in the triangle's own space.
 __device__ __forceinline__ void test_triangle(const float4 a, const float4 b, const float4 c, const RayT& r, int hitSide,
-                                              uint32_t slot, const TriRec* tris, HitT& best, uint32_t& bestPrim) {
+                                              uint32_t slot, const TriRec* tris, HitT& best, uint32_t& bestPrim,
+                                              uint32_t excl = 0x7FFFFFFFu) {
 #pragma clang fp contract(off)
     const float e1x = b.x, e1y = b.y, e1z = b.z;
     const float e2x = c.x, e2y = c.y, e2z = c.z;
@@ -123,6 +125,7 @@ __device__ __forceinline__ void test_triangle(const float4 a, const float4 b, co
         const bool front = (r.dx * gx + r.dy * gy + r.dz * gz) < 0.0f;
         if ((hitSide == RTX_HIT_FRONT && !front) || (hitSide == RTX_HIT_BACK && front)) return;
     }
+    if ((__float_as_uint(c.w) & TRI_OBJ_MASK) == excl) return;   // general kernels only (trav_verify); folds away when excl is the default
     best.t = t;
     best.u = u;
     best.v = v;
@@ -200,16 +203,17 @@ struct DevSceneT : DevScene {
 };
 template <class SC>
 __device__ __forceinline__ void test_primitive(const SC& sc, const float4 a, const float4 b, const float4 c, const RayT& r,
-                                               int hitSide, uint32_t slot, HitT& best, uint32_t& bestPrim) {
+                                               int hitSide, uint32_t slot, HitT& best, uint32_t& bestPrim, uint32_t excl) {
     const uint32_t kind = __float_as_uint(b.w);
-    if (kind == 0u) test_triangle(a, b, c, r, hitSide, slot, sc.tris, best, bestPrim);
+    if (!SC::kXF) excl = 0x7FFFFFFFu;   // (a constant there: the compare in test_triangle can never hold and goes away)
+    if (kind == 0u) test_triangle(a, b, c, r, hitSide, slot, sc.tris, best, bestPrim, excl);
     else if (!SC::kXF) return;   // identity meshes only (DevScene::has_xf == 0): no other kind of record exists
     else if (kind == RTX_KIND_XFTRI) {
         // a mesh under a non-identity node transform: the ray goes to node coordinates (direction not renormalised, so t
         // is the same parameter) and meets the object's own fp32 vertices (IntersectNodeAdapter.h:62 -> objects.cpp:140)
         float p[3], d[3];
         ray_to_object(sc, __float_as_uint(c.w) & TRI_OBJ_MASK, r, p, d);
-        test_triangle(a, b, c, RayT{p[0], p[1], p[2], d[0], d[1], d[2], r.tmax}, hitSide, slot, sc.tris, best, bestPrim);
+        test_triangle(a, b, c, RayT{p[0], p[1], p[2], d[0], d[1], d[2], r.tmax}, hitSide, slot, sc.tris, best, bestPrim, excl);
     } else
         test_analytic(sc, kind, __float_as_uint(c.w) & TRI_OBJ_MASK, __float_as_uint(a.w), r, hitSide, slot, best, bestPrim);
 }
@@ -227,7 +231,9 @@ struct TravState {
     uint32_t bestPrim;
     uint32_t cur;
     int sp;
+    uint32_t excl;           // general kernels: object left out of this traversal (its box culled it for this ray: trav_verify)
 };
+#define RTX_NO_OBJECT 0x7FFFFFFFu
 
 __device__ __forceinline__ void trav_init(TravState& s, const DevScene& sc, const RayT& r) {
     s.r = r;
@@ -241,6 +247,7 @@ __device__ __forceinline__ void trav_init(TravState& s, const DevScene& sc, cons
     s.bestPrim = 0xFFFFFFFFu;
     s.cur = sc.root;        // RTX_EMPTY_CHILD for an empty scene == DONE
     s.sp = 0;
+    s.excl = RTX_NO_OBJECT;
     // NaN or infinite origin / direction, NaN limit: no hit, as the reference's box test at the root decides for such a
     // ray (every comparison of scene_box.cpp:8-46 fails). The slab test here drops NaNs instead, so it has to be said.
     const float probe = (r.ox + r.oy + r.oz) + (r.dx + r.dy + r.dz);
@@ -373,7 +380,7 @@ __device__ __forceinline__ uint32_t trav_leaf_test(TravState& s, const SC& sc, u
         const float4 a = tris4[(size_t)slot * 3 + 0];
         const float4 b = tris4[(size_t)slot * 3 + 1];
         const float4 c = tris4[(size_t)slot * 3 + 2];
-        test_primitive(sc, a, b, c, s.r, hitSide, slot, s.best, s.bestPrim);
+        test_primitive(sc, a, b, c, s.r, hitSide, slot, s.best, s.bestPrim, s.excl);
     }
     return cnt;
 }
@@ -387,20 +394,54 @@ __device__ __forceinline__ uint32_t trav_leaf_step(TravState& s, const SC& sc, T
 
 // Closest hit along r within (EPS, r.tmax), run to completion by one lane (shadow chains, photons).
 // counters (optional): [0] += nodes visited, [1] += triangles tested.
+// The end of a traversal in the general kernels (SC::kXF): does the reference reach the hit it ended with? Its box tests
+// come first - the root's child box for the whole scene (IntersectNodeAdapter.h:30-32), the object's own box in node
+// coordinates for the object (:63-75) - and a hit within rounding of a box's silhouette fails them now and then
+// (ref_box_hit). Returns true when s.best stands (or has become a miss: root box); false when the object is culled for
+// this ray, in which case the traversal has been started again without it (TravState::excl) and the caller goes on
+// stepping. One object per ray: a second cull in one traversal is not followed (two silhouettes within rounding on one
+// ray). The lean kernels (world-space triangles only) return true at once: see ref_box_hit.
+template <class SC>
+__device__ __forceinline__ bool trav_verify(TravState& s, const SC& sc) {
+    if (!SC::kXF) return true;
+    if (s.best.slot < 0) return true;
+    const RayT r = s.r;
+    if (!ref_box_hit(sc.bounds, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.tmax)) {
+        s.best.t = r.tmax;
+        s.best.u = 0.0f;
+        s.best.v = 0.0f;
+        s.best.slot = -1;
+        s.bestPrim = 0xFFFFFFFFu;
+        return true;
+    }
+    const uint32_t kind = sc.tris[s.best.slot].kind, obj = sc.tris[s.best.slot].obj & TRI_OBJ_MASK;
+    if (kind != 0u && kind != RTX_KIND_XFTRI) return true;   // Sphere / Plane: tested on the way in (test_analytic)
+    float p[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
+    if (kind == RTX_KIND_XFTRI) ray_to_object(sc, obj, r, p, d);
+    if (ref_box_hit(sc.objXf[obj].box, p[0], p[1], p[2], d[0], d[1], d[2], r.tmax)) return true;
+    if (s.excl != RTX_NO_OBJECT) return true;
+    trav_init(s, sc, r);
+    s.excl = obj;
+    return false;
+}
+
 template <bool COUNT, class SC>
 __device__ __forceinline__ HitT traverse_closest(const SC& sc, const RayT& r, int hitSide, TravStack st,
                                                  uint32_t* nodeCount, uint32_t* triCount) {
     TravState s;
     trav_init(s, sc, r);
-    while (s.cur != RTX_TRAV_DONE) {
-        while (trav_is_inner(s.cur)) {
-            if (COUNT) (*nodeCount)++;
-            trav_inner_step(s, sc, st);
+    for (;;) {
+        while (s.cur != RTX_TRAV_DONE) {
+            while (trav_is_inner(s.cur)) {
+                if (COUNT) (*nodeCount)++;
+                trav_inner_step(s, sc, st);
+            }
+            if (s.cur != RTX_TRAV_DONE) {
+                const uint32_t n = trav_leaf_step(s, sc, st, hitSide);
+                if (COUNT) (*triCount) += n;
+            }
         }
-        if (s.cur != RTX_TRAV_DONE) {
-            const uint32_t n = trav_leaf_step(s, sc, st, hitSide);
-            if (COUNT) (*triCount) += n;
-        }
+        if (trav_verify(s, sc)) break;
     }
     return s.best;
 }
