@@ -230,7 +230,7 @@ def measured_traffic(a, world):
                world == 1)
     if not default or not os.path.exists(path):
         return None, None
-    # the non-counting instantiation of the extend kernel (extend_kernel<false> in round 1, <false, XF> since)
+    # the non-counting instantiation of the extend kernel (extend_kernel<false> in round 1, <false, XF, BOTH> since)
     k = next((v for n, v in json.load(open(path))["kernels"].items() if n.startswith("extend_kernel<false")), None)
     if not k or not k["dispatches"]:
         return None, None

@@ -58,8 +58,8 @@ uint32_t launch_raygen(const DevCamera& cam, const PathPool& pool, const int* pi
                        const SegQ& qOut, uint32_t* queueOut, int initGuides, hipStream_t stream);
 uint32_t launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm, const SegQ& qIn,
                       const uint32_t* queueIn, uint32_t n, int bounce, int maxBounces, unsigned long long seed, int sBase, int S,
-                      const int* pixels, const SegQ& qOut, uint32_t* queueOut, const SegQ& qShadow, int hasMicrofacet,
-                      hipStream_t stream, uint32_t* keysOut = nullptr);
+                      const int* pixels, const SegQ& qOut, uint32_t* queueOut, const SegQ& qShadow, int materialKinds,
+                      hipStream_t stream, uint32_t* keysOut = nullptr);   // materialKinds: bit 0 MtlMicrofacet, bit 1 MtlPhong present
 // ray regrouping (kernels_sort.hip): path slots of queue (qIn, items) in the order of the keys shade wrote -> pool.sortItems
 size_t sort_temp_bytes(uint32_t n);
 int launch_sort_shade_queue(const DevScene& sc, const PathPool& pool, const SegQ& qIn, const uint32_t* items, uint32_t n, void* temp,

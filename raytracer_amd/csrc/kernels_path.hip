@@ -141,7 +141,7 @@ __device__ __forceinline__ uint32_t ray_sort_key(const DevScene& sc, const float
 #ifndef SHADE_WAVES_PER_EU
 #define SHADE_WAVES_PER_EU 3
 #endif
-template <bool MICRO>
+template <bool MICRO, bool PHOT, bool PHONG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES_PER_EU))) void shade_kernel(DevScene sc, DevCamera cam, PathPool pool, DevPhotonMap pm,
                                                     SegQ qIn, const uint32_t* __restrict__ queueIn, uint32_t n, int bounce,
                                                     int maxBounces, unsigned long long seed, int sBase, int S,
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
         slot = queueIn[segq_item_index(qtab, i)];
         const float4 ra = pool.rays[2 * (size_t)slot], rb = pool.rays[2 * (size_t)slot + 1];
         const float4 hv = pool.hits[slot];
-        alive = shade_body<MICRO, false>(sc, cam, pool, pm, slot, RayT{ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, ra.w},
+        alive = shade_body<MICRO, false, PHOT, PHONG>(sc, cam, pool, pm, slot, RayT{ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, ra.w},
                                          HitT{hv.x, hv.y, hv.z, __float_as_int(hv.w)}, bounce, maxBounces, seed, sBase, S, pixels, qShadow);
     }
     // ---- surviving paths -> next queue ----
@@ -522,16 +522,25 @@ uint32_t launch_raygen(const DevCamera& cam, const PathPool& pool, const int* pi
 }
 uint32_t launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm, const SegQ& qIn,
                       const uint32_t* queueIn, uint32_t n, int bounce, int maxBounces, unsigned long long seed, int sBase, int S,
-                      const int* pixels, const SegQ& qOut, uint32_t* queueOut, const SegQ& qShadow, int hasMicrofacet,
+                      const int* pixels, const SegQ& qOut, uint32_t* queueOut, const SegQ& qShadow, int materialKinds,
                       hipStream_t stream, uint32_t* keysOut) {
     if (!n) return 0;
     const uint32_t grid = (n + 255) / 256;
-    if (hasMicrofacet)
-        hipLaunchKernelGGL(shade_kernel<true>, dim3(grid), dim3(256), 0, stream, sc, cam, pool, pm, qIn, queueIn, n, bounce, maxBounces,
-                           seed, sBase, S, pixels, qOut, queueOut, qShadow, keysOut);
-    else
-        hipLaunchKernelGGL(shade_kernel<false>, dim3(grid), dim3(256), 0, stream, sc, cam, pool, pm, qIn, queueIn, n, bounce, maxBounces,
-                           seed, sBase, S, pixels, qOut, queueOut, qShadow, keysOut);
+#define RTX_LAUNCH_SHADE(M, P, G)                                                                                                    \
+    hipLaunchKernelGGL((shade_kernel<M, P, G>), dim3(grid), dim3(256), 0, stream, sc, cam, pool, pm, qIn, queueIn, n, bounce, maxBounces, \
+                       seed, sBase, S, pixels, qOut, queueOut, qShadow, keysOut)
+    // materialKinds: bit 0 = the scene holds MtlMicrofacet, bit 1 = MtlPhong; a caustics map selects the gather
+    switch ((materialKinds & 3) | (pm.n > 0 ? 4 : 0)) {
+        case 0: RTX_LAUNCH_SHADE(false, false, false); break;
+        case 1: RTX_LAUNCH_SHADE(true, false, false); break;
+        case 2: RTX_LAUNCH_SHADE(false, false, true); break;
+        case 3: RTX_LAUNCH_SHADE(true, false, true); break;
+        case 4: RTX_LAUNCH_SHADE(false, true, false); break;
+        case 5: RTX_LAUNCH_SHADE(true, true, false); break;
+        case 6: RTX_LAUNCH_SHADE(false, true, true); break;
+        default: RTX_LAUNCH_SHADE(true, true, true); break;
+    }
+#undef RTX_LAUNCH_SHADE
     return grid;
 }
 void launch_shadow(const DevScene& sc, const LaunchCfg& cfg, const PathPool& pool, const SegQ& q, uint32_t n, int useTransmittance) {

@@ -66,7 +66,9 @@ void launch_segq_identity(const SegQ& q, uint32_t n, hipStream_t stream) {
 #ifndef EXTEND_WAVES_PER_EU
 #define EXTEND_WAVES_PER_EU 6
 #endif
-template <bool COUNT, bool XF>
+// BOTH: hitSide is RTX_HIT_FRONT_AND_BACK (every ray of the render loop): the side test of objects.cpp:175-191 - a normalised
+// geometric normal per candidate - is then not compiled into the leaf step (19 ms of the C3 frame's extend time)
+template <bool COUNT, bool XF, bool BOTH>
 __global__ __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(EXTEND_WAVES_PER_EU))) void extend_kernel(DevScene scArg, const float4* __restrict__ rays, SegQ q,
                                                             const uint32_t* __restrict__ items, int hitSide, int withLights,
                                                             float4* __restrict__ hits, uint2* spill, unsigned long long* counters,
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(EXTE
 #endif
             if (nLeaf * LEAF_WEIGHT >= nInner) {
                 if (atLeaf) {
-                    const uint32_t nt = trav_leaf_step(s, sc, st, hitSide);
+                    const uint32_t nt = trav_leaf_step(s, sc, st, BOTH ? RTX_HIT_FRONT_AND_BACK : hitSide);
                     if (COUNT) triCount += nt;
                 }
             } else if (atInner) {
@@ -155,15 +157,18 @@ void launch_extend_queue(const DevScene& sc, const LaunchCfg& cfg, const float4*
     const uint32_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
     const uint32_t grid = need < (uint32_t)cfg.gridBlocks ? need : (uint32_t)cfg.gridBlocks;
     const uint32_t chunk = segq_chunk(n, grid * (TRAV_BLOCK / 64));
-#define RTX_LAUNCH_EXTEND(C, X)                                                                                                  \
-    hipLaunchKernelGGL((extend_kernel<C, X>), dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, rays, q, items, hitSide, withLights, \
+#define RTX_LAUNCH_EXTEND(C, X, B)                                                                                                  \
+    hipLaunchKernelGGL((extend_kernel<C, X, B>), dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, rays, q, items, hitSide, withLights, \
                        hits, cfg.spill, cfg.counters, chunk)
-    if (cfg.counting) {
-        if (sc.has_xf) RTX_LAUNCH_EXTEND(true, true);
-        else RTX_LAUNCH_EXTEND(true, false);
-    } else {
-        if (sc.has_xf) RTX_LAUNCH_EXTEND(false, true);
-        else RTX_LAUNCH_EXTEND(false, false);
+    switch ((cfg.counting ? 4 : 0) | (sc.has_xf ? 2 : 0) | (hitSide == RTX_HIT_FRONT_AND_BACK ? 1 : 0)) {
+        case 0: RTX_LAUNCH_EXTEND(false, false, false); break;
+        case 1: RTX_LAUNCH_EXTEND(false, false, true); break;
+        case 2: RTX_LAUNCH_EXTEND(false, true, false); break;
+        case 3: RTX_LAUNCH_EXTEND(false, true, true); break;
+        case 4: RTX_LAUNCH_EXTEND(true, false, false); break;
+        case 5: RTX_LAUNCH_EXTEND(true, false, true); break;
+        case 6: RTX_LAUNCH_EXTEND(true, true, false); break;
+        default: RTX_LAUNCH_EXTEND(true, true, true); break;
     }
 #undef RTX_LAUNCH_EXTEND
 }
@@ -287,7 +292,7 @@ void launch_visibility(const DevScene& sc, const LaunchCfg& cfg, const float4* r
 int query_resident_blocks(int which) {
     int nb = 0;
     hipError_t e;
-    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, extend_kernel<false, false>, TRAV_BLOCK, 0);
+    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, extend_kernel<false, false, true>, TRAV_BLOCK, 0);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, visibility_kernel<false>, TRAV_BLOCK, 0);
     if (e != hipSuccess || nb < 1) nb = 2;
     return nb;

@@ -126,5 +126,8 @@ struct DevScene {
     float bg[3];  int bg_tex;
     float bg_emission;
     int has_xf;             // some record is not a world-space triangle (a mesh under a non-identity node transform, a Sphere, a Plane): selects the kernel
+    // what a function templated on the scene type may assume: DevSceneT<false> (traverse.h) overrides this with "world-space
+    // triangles only"; a plain DevScene makes no such promise
+    static constexpr bool kXF = true;
                             // instantiations that carry the object-space triangle test (traverse.h DevSceneT)
 };

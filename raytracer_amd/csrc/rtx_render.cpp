@@ -414,7 +414,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                     shadeQ = s->cfg.identQ;
                 }
                 const uint32_t gridShade = launch_shade(s->dev, dc, pool, pm, shadeQ, shadeItems, n, bounce, rp->max_bounces, rp->seed, sBase, Sp,
-                                                        curPixels, sqOut, qout, pool.qS, s->hasMicrofacet, st, sortRays ? pool.sortKeys : nullptr);
+                                                        curPixels, sqOut, qout, pool.qS, (s->hasMicrofacet ? 1 : 0) | (s->hasPhong ? 2 : 0), st, sortRays ? pool.sortKeys : nullptr);
                 tm.end(st);
                 launch_segq_scan2(sqOut, gridShade, 1, pool.qS, gridShade, shadowMult, 256, pool.totals, st);
                 uint32_t cnt[2] = {0, 0};

@@ -88,11 +88,17 @@ __device__ __forceinline__ void resolve_slot(const PathPool& pool, uint32_t slot
 // MICRO: the scene holds MtlMicrofacet materials (a second BSDF in the kernel; scenes without them run the leaner one).
 // TAIL: the caller is tail_kernel, which walks a path to its end inside one kernel: the shadow segment of light l goes
 // to the fixed entry slot * lights + l of pool.shadowQ instead of the shadow queue; the kernel traces it and resolves.
-template <bool MICRO, bool TAIL>
-__device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm,
+// PHOT: a caustics map may be present (pm.n decides at run time); false: the gather is not compiled in (it costs the
+// shade kernel 8 ms per C3 frame just by being there).
+// PHONG: the scene holds MtlPhong materials; false: only the Blinn form of the lobes is compiled in (the Phong form costs
+// the kernel 26 ms per C3 frame by being there: every material of cerealBar.xml is MtlBlinn).
+template <bool MICRO, bool TAIL, bool PHOT = true, bool PHONG = true>
+__device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pmArg,
                                            uint32_t slot, const RayT& ray, const HitT& h, int bounce, int maxBounces,
                                            unsigned long long seed, int sBase, int S, const int* __restrict__ pixels,
                                            const SegQ& qShadow) {
+    DevPhotonMap pm = pmArg;
+    if (!PHOT) pm.n = 0;   // every `pm.n > 0` below folds to false
     bool alive = false;
     const uint32_t cap = pool.capacity;
     const uint32_t shadowMult = (uint32_t)max(1, sc.n_lights);
@@ -196,7 +202,7 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
             MicroCtx mctx;
             if (micro) mctx = build_micro_ctx(sc, *mtl, sx);
             else ctx = build_phong_ctx(sc, *mtl, sx);
-            const bool phong = mtl->type == RTX_MTL_PHONG;
+            const bool phong = PHONG && mtl->type == RTX_MTL_PHONG;
 
             // ---- next event estimation: contributions now, visibility by the shadow kernel (:456-503) ----
             const bool photonSurface = mtl_is_photon_surface(*mtl);

@@ -12,11 +12,12 @@ __device__ __forceinline__ f3 offset_point(f3 p, f3 n, f3 dir) {
 }
 
 // Geometric normal + front flag of a triangle hit (objects.cpp:175-177,190) without the rest of HitInfo.
-__device__ __forceinline__ void triangle_gn(const DevScene& sc, const RayT& r, int slot, float t, f3& GN, bool& front, int& obj) {
+template <class SC>
+__device__ __forceinline__ void triangle_gn(const SC& sc, const RayT& r, int slot, float t, f3& GN, bool& front, int& obj) {
     const float4* tris4 = reinterpret_cast<const float4*>(sc.tris);
     const float4 b = tris4[(size_t)slot * 3 + 1];
     const float4 c = tris4[(size_t)slot * 3 + 2];
-    if (__float_as_uint(b.w) != 0u) {   // Sphere / Plane / mesh under a node transform: through the object's space
+    if (SC::kXF && __float_as_uint(b.w) != 0u) {   // Sphere / Plane / mesh under a node transform: through the object's space
         SurfHit sh;
         resolve_triangle(sc, r, HitT{t, 0.0f, 0.0f, slot}, sh);
         GN = sh.GN;
@@ -35,13 +36,14 @@ __device__ __forceinline__ void triangle_gn(const DevScene& sc, const RayT& r, i
 // End of one hop of the chain (RayCaster.cpp:205-276): h is the closest hit of the segment (o, d, maxDist), lights
 // included. Returns true when the chain ends (value in `result`), false when the next hop starts from the updated
 // (o, maxDist) with the updated running visibility.
-__device__ __forceinline__ bool shadow_hop_end(const DevScene& sc, f3& o, f3 d, float& maxDist, const HitT& h, bool useTransmittance,
+template <class SC>
+__device__ __forceinline__ bool shadow_hop_end(const SC& sc, f3& o, f3 d, float& maxDist, const HitT& h, bool useTransmittance,
                                                int& hop, float& visibility, float& result) {
     result = visibility;
     if (h.slot == -1) return true;   // nothing blocking
     if (h.slot <= -2) return true;   // hit the light itself
     f3 hp = o + d * h.t;
-    if (sc.tris[h.slot].kind != 0u) {   // HitInfo::p comes back through the node transform (IntersectNodeAdapter.h:93)
+    if (SC::kXF && sc.tris[h.slot].kind != 0u) {   // HitInfo::p comes back through the node transform (IntersectNodeAdapter.h:93); lean scenes hold no such record
         SurfHit sh;
         resolve_triangle(sc, RayT{o.x, o.y, o.z, d.x, d.y, d.z, maxDist}, HitT{h.t, 0.0f, 0.0f, h.slot}, sh);
         hp = sh.p;
