@@ -61,6 +61,9 @@ struct PhongCtx {
 };
 
 // Shading.cpp:227-278 — built ONCE per hit (the reference rebuilds it for every GenerateSample/GetSampleInfo call)
+// SPECTEX = false: no material of the scene puts a texture on Specular / Reflection / Refraction / Glossiness (a scene fact,
+// rtx_scene::generalMtl): the four inlined texture fetches are then not compiled in
+template <bool SPECTEX = true>
 __device__ __forceinline__ PhongCtx build_phong_ctx(const DevScene& sc, const DevMaterial& m, const SampCtx& s) {
     PhongCtx c;
     c.N = normalized3(s.N);
@@ -68,10 +71,10 @@ __device__ __forceinline__ PhongCtx build_phong_ctx(const DevScene& sc, const De
     c.V = safe_normalize3(s.V);
     c.R = safe_normalize3(reflect3(-c.V, c.N));
     c.kd = eval_tc(sc, m.kd, m.kd_tex, s.uvw);
-    c.ks = eval_tc(sc, m.ks, m.ks_tex, s.uvw);
-    c.kr = eval_tc(sc, m.kr, m.kr_tex, s.uvw);
-    c.kt = eval_tc(sc, m.kt, m.kt_tex, s.uvw);
-    c.alpha = fmaxf(0.001f, eval_tf(sc, m.gloss, m.gloss_tex, s.uvw));
+    c.ks = eval_tc(sc, m.ks, SPECTEX ? m.ks_tex : -1, s.uvw);
+    c.kr = eval_tc(sc, m.kr, SPECTEX ? m.kr_tex : -1, s.uvw);
+    c.kt = eval_tc(sc, m.kt, SPECTEX ? m.kt_tex : -1, s.uvw);
+    c.alpha = fmaxf(0.001f, eval_tf(sc, m.gloss, SPECTEX ? m.gloss_tex : -1, s.uvw));
     c.ior = m.ior;
     c.kd = clamp_max3(c.kd, 1.0f);
     c.ks = clamp_max3(c.ks, 1.0f);

@@ -201,6 +201,8 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
         o.type = m.type;
         if (m.type == RTX_MTL_MICROFACET) s->hasMicrofacet = 1;
         if (m.type == RTX_MTL_PHONG) s->hasPhong = 1;
+        // ... or a texture on Specular / Reflection / Refraction / Glossiness (a MtlMicrofacet reads its own maps in build_micro_ctx)
+        if (m.type != RTX_MTL_MICROFACET && (m.specular_tex >= 0 || m.reflection_tex >= 0 || m.refraction_tex >= 0 || m.glossiness_tex >= 0)) s->hasPhong = 1;
         std::memcpy(o.kd, m.diffuse, 12);    o.kd_tex = m.diffuse_tex;
         std::memcpy(o.ks, m.specular, 12);   o.ks_tex = m.specular_tex;
         std::memcpy(o.kr, m.reflection, 12); o.kr_tex = m.reflection_tex;

@@ -33,7 +33,8 @@ struct rtx_scene {
     LaunchCfg cfg{};
     int numCUs = 0;
     int hasMicrofacet = 0;        // some material is RTX_MTL_MICROFACET: selects the two-BSDF shade kernel
-    int hasPhong = 0;             // some material is RTX_MTL_PHONG: selects the shade kernel that carries the Phong form of the lobes
+    int hasPhong = 0;             // some material is RTX_MTL_PHONG or textures Specular / Reflection / Refraction / Glossiness: selects the
+                                  // shade kernel that carries the Phong form of the lobes and those texture fetches
     std::atomic<int> cancel{0};   // rtx_cancel
     // reusable scratch for the host-array entry points
     DevBuf rays, hits, full, aux, aux2;

@@ -90,8 +90,10 @@ __device__ __forceinline__ void resolve_slot(const PathPool& pool, uint32_t slot
 // to the fixed entry slot * lights + l of pool.shadowQ instead of the shadow queue; the kernel traces it and resolves.
 // PHOT: a caustics map may be present (pm.n decides at run time); false: the gather is not compiled in (it costs the
 // shade kernel 8 ms per C3 frame just by being there).
-// PHONG: the scene holds MtlPhong materials; false: only the Blinn form of the lobes is compiled in (the Phong form costs
-// the kernel 26 ms per C3 frame by being there: every material of cerealBar.xml is MtlBlinn).
+// PHONG ("general materials"): the scene holds MtlPhong materials, or textures on Specular / Reflection / Refraction /
+// Glossiness; false: only the Blinn form of the lobes and only the Diffuse / Emission / bump textures are compiled in (the
+// Phong form costs the kernel 26 ms per C3 frame by being there, the four texture fetches 10 ms: every material of
+// cerealBar.xml is MtlBlinn, textured in Diffuse, Emission and bump only).
 template <bool MICRO, bool TAIL, bool PHOT = true, bool PHONG = true>
 __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pmArg,
                                            uint32_t slot, const RayT& ray, const HitT& h, int bounce, int maxBounces,
@@ -201,7 +203,7 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
             PhongCtx ctx;
             MicroCtx mctx;
             if (micro) mctx = build_micro_ctx(sc, *mtl, sx);
-            else ctx = build_phong_ctx(sc, *mtl, sx);
+            else ctx = build_phong_ctx<PHONG>(sc, *mtl, sx);
             const bool phong = PHONG && mtl->type == RTX_MTL_PHONG;
 
             // ---- next event estimation: contributions now, visibility by the shadow kernel (:456-503) ----
