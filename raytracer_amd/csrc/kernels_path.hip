@@ -101,9 +101,7 @@ __global__ void raygen_kernel(DevCamera cam, PathPool pool, const int* __restric
             }
             pool.rays[2 * (size_t)slot] = make_float4(ro.x, ro.y, ro.z, RTX_BIG);
             pool.rays[2 * (size_t)slot + 1] = make_float4(rd.x, rd.y, rd.z, 0.0f);
-            pool.L[slot] = make_float4(0.0f, 0.0f, 0.0f, RTX_BIG);
-            pool.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-            pool.medium[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(PF_LAST_DELTA));
+            // L / beta / medium start as {0, BIG}, {1, 1}, {0, PF_LAST_DELTA}: the shading of bounce 0 assumes that (shade_body.h)
             if (initGuides) {
                 pool.pendBeta[slot] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);   // nothing to resolve (resolve_add)
                 pool.albedo[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);

@@ -105,9 +105,15 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
     const uint32_t cap = pool.capacity;
     const uint32_t shadowMult = (uint32_t)max(1, sc.n_lights);
     {
-        float4 L4 = pool.L[slot];
-        float4 b4 = pool.beta[slot];
-        float4 m4 = pool.medium[slot];
+        // a camera ray carries the initial path state (raygen_kernel does not write it out: 48 B per path saved each way)
+        float4 L4 = make_float4(0.0f, 0.0f, 0.0f, RTX_BIG);
+        float4 b4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        float4 m4 = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(PF_LAST_DELTA));
+        if (bounce > 0) {
+            L4 = pool.L[slot];
+            b4 = pool.beta[slot];
+            m4 = pool.medium[slot];
+        }
         f3 L = mk3(L4.x, L4.y, L4.z);
         if (bounce > 0) resolve_add(pool, slot, sc.n_lights, pm.n > 0, L);   // the NEE of the previous vertex (its shadow results are in)
         f3 beta = mk3(b4.x, b4.y, b4.z);
