@@ -45,8 +45,11 @@ struct LgState {
     LgCall stack[LG_STACK];
 };
 
-template <class SC>
+// PLAIN: Blinn materials only and no photon maps in this call (launch_legacy decides): the Phong and microfacet forms of
+// Shade() and the two photon gathers are then not compiled in (the same specialisation as shade_kernel's)
+template <class SC, bool PLAIN = false>
 struct LgSceneT {
+    static constexpr bool kPlain = PLAIN;
     const SC& sc;
     const DevPhotonMap& pmGlobal;
     const DevPhotonMap& pmCaustic;
@@ -283,8 +286,9 @@ __device__ __forceinline__ f3 lg_glossy_dir(const SampCtx& sx, f3 axis, float al
 }
 
 // legacy GenerateSample: MtlBlinn :697-788, MtlPhong :790-874, MtlMicrofacet :876-897
+template <bool PLAIN>
 __device__ __forceinline__ bool lg_generate_sample(const DevScene& sc, const DevMaterial& m, const SampCtx& s, f3& dir, DirInfo& si) {
-    if (m.type == RTX_MTL_MICROFACET) {
+    if (!PLAIN && m.type == RTX_MTL_MICROFACET) {
         const f3 N = normalized3(s.N);
         f3 U, Vb;
         build_onb(N, U, Vb);
@@ -298,7 +302,7 @@ __device__ __forceinline__ bool lg_generate_sample(const DevScene& sc, const Dev
         si.lobe = LOBE_DIFFUSE;
         return true;
     }
-    const bool phong = m.type == RTX_MTL_PHONG;
+    const bool phong = !PLAIN && m.type == RTX_MTL_PHONG;
     f3 N = normalized3(s.N);
     if (!s.front) N = -N;
     const f3 V = normalized3(s.V);
@@ -375,7 +379,7 @@ __device__ __forceinline__ void lg_shade(const G& g, const DevMaterial& m, const
     const auto& sc = g.sc;
     const bool canBounce = bounce < LG_MAX_BOUNCES;
     const uint32_t node = sx.stream;
-    if (m.type == RTX_MTL_MICROFACET) {
+    if (!G::kPlain && m.type == RTX_MTL_MICROFACET) {
         const f3 N = normalized3(sx.N);
         const f3 base = eval_tc(sc, m.kd, m.kd_tex, sx.uvw);
         f3 result = mk3(0.0f);
@@ -392,7 +396,7 @@ __device__ __forceinline__ void lg_shade(const G& g, const DevMaterial& m, const
         if (max3c(base) > 1e-6f && canBounce) {
             f3 indirDir;
             DirInfo si;
-            if (lg_generate_sample(sc, m, sx, indirDir, si)) lg_push(S, sx, indirDir, w * si.mult, mk3(0.0f), node * 3u + 1u, bounce + 1, diffuseDepth);
+            if (lg_generate_sample<G::kPlain>(sc, m, sx, indirDir, si)) lg_push(S, sx, indirDir, w * si.mult, mk3(0.0f), node * 3u + 1u, bounce + 1, diffuseDepth);
         }
         if (bounce == 0 && DEFER) {   // queued last = traced first: the stack never holds the shadow queries of two Shade() calls
             for (int l = 0; l < sc.n_lights; ++l) {
@@ -406,7 +410,7 @@ __device__ __forceinline__ void lg_shade(const G& g, const DevMaterial& m, const
         S.L = S.L + w * result;
         return;
     }
-    const bool phong = m.type == RTX_MTL_PHONG;
+    const bool phong = !G::kPlain && m.type == RTX_MTL_PHONG;
     f3 N = normalized3(sx.N);
     if (!sx.front) N = -N;
     const f3 V = normalized3(sx.V);
@@ -448,14 +452,14 @@ __device__ __forceinline__ void lg_shade(const G& g, const DevMaterial& m, const
     // indirect light (:419-457)
     f3 indirect = mk3(0.0f), causticTerm = mk3(0.0f);
     const bool hasDiffuse = max3c(kd) > 1e-6f;
-    if (hasDiffuse && g.pmCaustic.n > 0) causticTerm = (kd / PI_F) * estimate_irradiance(g.pmCaustic, sx.P, sx.N);
+    if (!G::kPlain && hasDiffuse && g.pmCaustic.n > 0) causticTerm = (kd / PI_F) * estimate_irradiance(g.pmCaustic, sx.P, sx.N);
     f3 diffDir = mk3(0.0f), diffW = mk3(0.0f);
     bool pushDiffuse = false;
-    if (g.pmGlobal.n > 0 && !(diffuseDepth <= 1)) {
+    if (!G::kPlain && g.pmGlobal.n > 0 && !(diffuseDepth <= 1)) {
         indirect = indirect + (kd / PI_F) * estimate_irradiance(g.pmGlobal, sx.P, sx.N);
     } else if (hasDiffuse && canBounce) {
         DirInfo si;
-        if (lg_generate_sample(sc, m, sx, diffDir, si)) {
+        if (lg_generate_sample<G::kPlain>(sc, m, sx, diffDir, si)) {
             diffW = wLocal * (si.mult / si.prob);
             pushDiffuse = true;
         }
@@ -580,7 +584,7 @@ __device__ __forceinline__ void lg_run(const G& g, unsigned long long key, LgSta
 #ifndef LEGACY_WAVES_PER_EU
 #define LEGACY_WAVES_PER_EU 3
 #endif
-template <bool XF>
+template <bool XF, bool PLAIN>
 __attribute__((amdgpu_waves_per_eu(LEGACY_WAVES_PER_EU)))
 __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene scArg, DevCamera cam, PathPool pool, DevPhotonMap pmGlobal,
                                                             DevPhotonMap pmCaustic, SegQ qIn, const uint32_t* __restrict__ queueIn,
@@ -592,7 +596,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene scArg, DevC
     __syncthreads();
     const DevSceneT<XF> sc(scArg);
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, nThreads = gridDim.x * blockDim.x;
-    const LgSceneT<DevSceneT<XF>> g{sc, pmGlobal, pmCaustic, TravStack{&lds_stack[threadIdx.x], spill + gtid, nThreads}};
+    const LgSceneT<DevSceneT<XF>, PLAIN> g{sc, pmGlobal, pmCaustic, TravStack{&lds_stack[threadIdx.x], spill + gtid, nThreads}};
     unsigned long long rays = 0, shadows = 0;
     // Every lane is a small state machine: it holds one camera sample and its stack of pending calls (secondary rays and
     // the shadow queries of the Shade() just evaluated), and at most one ray in flight. The wave runs ONE kind of step per
@@ -763,7 +767,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene scArg, DevC
         sx.key = key;
         sx.stream = c.node;
         if (isRoot) {
-            const f3 alb = m.type == RTX_MTL_MICROFACET ? mk3(0.5f) : eval_tc(sc, m.kd, m.kd_tex, sx.uvw);   // GetDiffuseAlbedo :135-138
+            const f3 alb = (!PLAIN && m.type == RTX_MTL_MICROFACET) ? mk3(0.5f) : eval_tc(sc, m.kd, m.kd_tex, sx.uvw);   // GetDiffuseAlbedo :135-138
             pool.albedo[slot] = make_float4(alb.x, alb.y, alb.z, 1.0f);
         }
         const int bounce = (int)(c.bounceDepth & 0xFFu);
@@ -824,14 +828,20 @@ void launch_legacy_secondary(const DevScene& sc, const LaunchCfg& cfg, const Dev
 
 void launch_legacy(const DevScene& sc, const LaunchCfg& cfg, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pmGlobal,
                    const DevPhotonMap& pmCaustic, const SegQ& qIn, const uint32_t* queueIn, uint32_t n, unsigned long long seed,
-                   int sBase, int S, const int* pixels) {
+                   int sBase, int S, const int* pixels, int blinnOnly) {
     if (!n) return;
     const uint32_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
     const uint32_t grid = need < (uint32_t)cfg.gridBlocks ? need : (uint32_t)cfg.gridBlocks;
-    if (sc.has_xf)
-        hipLaunchKernelGGL(legacy_kernel<true>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, cam, pool, pmGlobal, pmCaustic, qIn, queueIn,
-                           n, seed, sBase, S, pixels, cfg.spill);
-    else
-        hipLaunchKernelGGL(legacy_kernel<false>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, cam, pool, pmGlobal, pmCaustic, qIn, queueIn,
-                           n, seed, sBase, S, pixels, cfg.spill);
+    const bool plain = blinnOnly && pmGlobal.n <= 0 && pmCaustic.n <= 0;
+#define RTX_LAUNCH_LEGACY(X, P)                                                                                                          \
+    hipLaunchKernelGGL((legacy_kernel<X, P>), dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, cam, pool, pmGlobal, pmCaustic, qIn, queueIn, \
+                       n, seed, sBase, S, pixels, cfg.spill)
+    if (sc.has_xf) {
+        if (plain) RTX_LAUNCH_LEGACY(true, true);
+        else RTX_LAUNCH_LEGACY(true, false);
+    } else {
+        if (plain) RTX_LAUNCH_LEGACY(false, true);
+        else RTX_LAUNCH_LEGACY(false, false);
+    }
+#undef RTX_LAUNCH_LEGACY
 }

@@ -381,7 +381,8 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 tm.end(st);
                 out.extend_launches++;
                 tm.begin(2, st);
-                launch_legacy(s->dev, s->cfg, dc, pool, pmGlobal, pm, sqIn, qin, n, rp->seed, sBase, Sp, curPixels);
+                launch_legacy(s->dev, s->cfg, dc, pool, pmGlobal, pm, sqIn, qin, n, rp->seed, sBase, Sp, curPixels,
+                              (!s->hasMicrofacet && !s->hasPhong) ? 1 : 0);
                 tm.end(st);
                 RTX_HIP(hipStreamSynchronize(st));   // one pass at a time, so that rtx_cancel is seen between passes
                 n = 0;
