@@ -129,7 +129,8 @@ __global__ __launch_bounds__(TRAV_BLOCK) void tail_kernel(DevScene scArg, DevCam
         if (haveVertex) resolve_slot(pool, slot, nL, usePhotons != 0);
         haveVertex = false;
         if (needExtend) {
-            needExtend = shade_body<MICRO, true>(sc, cam, pool, pm, slot, ray, hit, bounce, maxBounces, seed, sBase, S, pixels, SegQ{nullptr});
+            // MICRO here = "general": microfacet or Phong materials, textured specular terms, or a caustics map (launch_tail)
+            needExtend = shade_body<MICRO, true, MICRO, MICRO>(sc, cam, pool, pm, slot, ray, hit, bounce, maxBounces, seed, sBase, S, pixels, SegQ{nullptr});
             // the NEE entries are this vertex's only when the body left something pending (a path that ended on a miss
             // or a light never reached its NEE loop: the entries then hold an older vertex's values)
             haveVertex = pool.pendBeta[slot].w >= 0.0f;
@@ -152,7 +153,7 @@ void launch_tail(const DevScene& sc, const LaunchCfg& cfg, const DevCamera& cam,
 #define RTX_LAUNCH_TAIL(M, X)                                                                                                         \
     hipLaunchKernelGGL((tail_kernel<M, X>), dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, cam, pool, pm, qIn, queueIn, bounce0, maxBounces, \
                        seed, sBase, S, pixels, usePhotons, cfg.spill, chunk)
-    if (hasMicrofacet) {
+    if (hasMicrofacet || usePhotons) {   // hasMicrofacet: any material beyond plain Blinn (rtx_render.cpp)
         if (sc.has_xf) RTX_LAUNCH_TAIL(true, true);
         else RTX_LAUNCH_TAIL(true, false);
     } else {

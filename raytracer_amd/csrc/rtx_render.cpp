@@ -453,7 +453,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                     tm.nextItems = n;
                     tm.begin(2, st);
                     launch_tail(s->dev, s->cfg, dc, pool, pm, sqIn, qin, n, bounce + 1, rp->max_bounces, rp->seed, sBase, Sp, curPixels,
-                                s->hasMicrofacet, pm.n > 0 ? 1 : 0);
+                                (s->hasMicrofacet || s->hasPhong) ? 1 : 0, pm.n > 0 ? 1 : 0);
                     tm.end(st);
                     n = 0;
                 }
