@@ -34,7 +34,7 @@ void launch_extend(const DevScene& sc, const LaunchCfg& cfg, const float4* rays,
 void launch_extend_queue(const DevScene& sc, const LaunchCfg& cfg, const float4* rays, const SegQ& q, const uint32_t* items,
                          uint32_t n, int hitSide, int withLights, float4* hits);
 void launch_segq_scan2(const SegQ& qa, uint32_t Ga, uint32_t multA, const SegQ& qb, uint32_t Gb, uint32_t multB, uint32_t blockThreads,
-                       uint32_t* totals, hipStream_t stream);
+                       uint32_t* totals, hipStream_t stream, unsigned long long* acc = nullptr);
 // CameraAdapter.h:7-27 pixel-centre rays for the whole image
 void launch_primary_raygen(const DevCamera& cam, float4* rays, hipStream_t stream);
 // compact hit -> full rtx_hit (device array)
@@ -67,7 +67,9 @@ int launch_sort_shade_queue(const DevScene& sc, const PathPool& pool, const SegQ
 int launch_sort_queue(const PathPool& pool, const SegQ& qIn, const uint32_t* items, uint32_t n, void* temp, size_t tempBytes,
                       hipStream_t stream);
 // the rest of a pass for its last n paths in one kernel (n <= RTX_TAIL_MAX_PATHS)
+#ifndef RTX_TAIL_MAX_PATHS
 #define RTX_TAIL_MAX_PATHS 65536u
+#endif
 void launch_tail(const DevScene& sc, const LaunchCfg& cfg, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm,
                  const SegQ& qIn, const uint32_t* queueIn, uint32_t n, int bounce0, int maxBounces, unsigned long long seed, int sBase,
                  int S, const int* pixels, int hasMicrofacet, int usePhotons);

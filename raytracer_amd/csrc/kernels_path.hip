@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool alive = false;
     uint32_t slot = 0;
-    if (i < n) {
+    // n may be an upper bound (the host does not read every bounce's count back): the queue's own total decides
+    if (i < n && i < qtab[QSEG]) {
         slot = queueIn[segq_item_index(qtab, i)];
         const float4 ra = pool.rays[2 * (size_t)slot], rb = pool.rays[2 * (size_t)slot + 1];
         const float4 hv = pool.hits[slot];

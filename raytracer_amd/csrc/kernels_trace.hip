@@ -8,7 +8,7 @@
 // ---- segmented queue control (segqueue.h) ---------------------------------------------------------------------
 // One wave per queue: lane s owns segment s.
 __global__ void segq_scan_kernel(SegQ qa, uint32_t Ga, uint32_t Ba, uint32_t multA, SegQ qb, uint32_t Gb, uint32_t Bb, uint32_t multB,
-                                 uint32_t* totals, uint32_t slotA, uint32_t slotB) {
+                                 uint32_t* totals, uint32_t slotA, uint32_t slotB, unsigned long long* acc) {
     const SegQ q = blockIdx.x == 0 ? qa : qb;
     const uint32_t G = blockIdx.x == 0 ? Ga : Gb, B = blockIdx.x == 0 ? Ba : Bb, mult = blockIdx.x == 0 ? multA : multB;
     const uint32_t l = threadIdx.x;
@@ -22,6 +22,7 @@ __global__ void segq_scan_kernel(SegQ qa, uint32_t Ga, uint32_t Ba, uint32_t mul
     if (l == 63u) {
         q.ctl[SEGQ_PREFIX + QSEG] = x;
         totals[blockIdx.x == 0 ? slotA : slotB] = x;
+        if (acc) acc[blockIdx.x] += x;   // one scan at a time per stream: running sums of the entries produced (rtx_render.cpp)
     }
     q.ctl[SEGQ_START + l] = segq_first_block(l, G) * B * mult;
     q.ctl[SEGQ_COUNT + l * QSTRIDE] = 0u;
@@ -39,12 +40,12 @@ __global__ void segq_identity_kernel(SegQ q, uint32_t n) {
 void launch_segq_scan(const SegQ& q, uint32_t producerBlocks, uint32_t blockThreads, uint32_t mult, uint32_t* totals,
                       uint32_t totalsSlot, hipStream_t stream) {
     hipLaunchKernelGGL(segq_scan_kernel, dim3(1), dim3(64), 0, stream, q, producerBlocks ? producerBlocks : 1u, blockThreads, mult, q, 1u,
-                       blockThreads, mult, totals, totalsSlot, totalsSlot);
+                       blockThreads, mult, totals, totalsSlot, totalsSlot, (unsigned long long*)nullptr);
 }
 void launch_segq_scan2(const SegQ& qa, uint32_t Ga, uint32_t multA, const SegQ& qb, uint32_t Gb, uint32_t multB, uint32_t blockThreads,
-                       uint32_t* totals, hipStream_t stream) {
+                       uint32_t* totals, hipStream_t stream, unsigned long long* acc) {
     hipLaunchKernelGGL(segq_scan_kernel, dim3(2), dim3(64), 0, stream, qa, Ga ? Ga : 1u, blockThreads, multA, qb, Gb ? Gb : 1u, blockThreads,
-                       multB, totals, 0u, 1u);
+                       multB, totals, 0u, 1u, acc);
 }
 void launch_segq_identity(const SegQ& q, uint32_t n, hipStream_t stream) {
     hipLaunchKernelGGL(segq_identity_kernel, dim3(1), dim3(64), 0, stream, q, n);

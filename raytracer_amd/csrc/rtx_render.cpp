@@ -23,6 +23,7 @@ struct PathPoolHost {
     // second stream: the shadow kernel of bounce k runs beside the extend kernel of bounce k+1
     hipStream_t sideStream = nullptr;
     hipEvent_t sideDone = nullptr;
+    hipEvent_t mainMark = nullptr;   // recorded on the main stream after a bounce's scan when the host does not synchronise there
     void* sortTemp = nullptr;     // in allocs
     hipEvent_t evTotal0 = nullptr, evTotal1 = nullptr;   // whole-call timing; owned here so that no error path leaks them
     uint2* sideSpill = nullptr;   // its own traversal spill slab (both kernels are in flight at once)
@@ -32,6 +33,10 @@ struct PathPoolHost {
             (void)hipStreamSynchronize(sideStream);
             (void)hipStreamDestroy(sideStream);
             sideStream = nullptr;
+        }
+        if (mainMark) {
+            (void)hipEventDestroy(mainMark);
+            mainMark = nullptr;
         }
         if (sideDone) {
             (void)hipEventDestroy(sideDone);
@@ -335,6 +340,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     if (overlap && !legacy && !ph->sideStream) {
         RTX_HIP(hipStreamCreateWithFlags(&ph->sideStream, hipStreamNonBlocking));
         RTX_HIP(hipEventCreateWithFlags(&ph->sideDone, hipEventDisableTiming));
+        RTX_HIP(hipEventCreateWithFlags(&ph->mainMark, hipEventDisableTiming));
         if ((rc = pool_alloc(ph, &ph->sideSpill, (size_t)s->cfg.gridBlocks * TRAV_BLOCK * STACK_GLOBAL)) != RTX_OK) {
             rtx_scene_release_pool(s);   // stream, event and every pool allocation; the next call starts from scratch
             return rc;
@@ -353,6 +359,16 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     const bool sortRays = pool.sortKeys && eSortRays && std::atoi(eSortRays) != 0;
     const bool sortShade = pool.sortKeys && eSortShadeRun && std::atoi(eSortShadeRun) != 0;   // where the sort's time is booked (extend or shade)
 
+    // The counts of a bounce (paths alive, shadow segments) come back to the host every syncEvery-th bounce only; in between
+    // the launches are sized by the last known counts, which bound the later ones from above (paths only die), the kernels
+    // take the true counts from the queues' control words, and the totals are summed on the device (pool.rayCounters[2..3]).
+    // Measured slower than a read-back per bounce (C3, 16 spp: 137.1 ms -> 139.3 / 140.8 / 145.2 ms at 2 / 4 / 8): grids sized by
+    // stale bounds run empty blocks and the tail kernel takes over later than it could, which costs more than the round
+    // trips save. Kept behind RTX_AMD_SYNC_EVERY for callers whose host thread is the bottleneck.
+    int syncEvery = 1;
+    if (const char* e = std::getenv("RTX_AMD_SYNC_EVERY")) syncEvery = std::max(1, std::atoi(e));
+    if (s->cfg.counting || sortRays || sortShade) syncEvery = 1;
+    unsigned long long handedOver = 0;   // paths counted by the device sums but not traced by an extend launch (tail kernel, bounce limit)
     s->cancel.store(0);
     PassTimers tm{ph};
     int* curPixels = pool.pixels;
@@ -387,9 +403,11 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 RTX_HIP(hipStreamSynchronize(st));   // one pass at a time, so that rtx_cancel is seen between passes
                 n = 0;
             }
+            bool exact = true;   // n is the true count (else an upper bound)
+            bool limitHit = false;
             for (int bounce = 0; bounce < rp->max_bounces && n > 0 && !s->cancel.load(std::memory_order_relaxed); ++bounce) {
                 if (bounce == 0) out.rays_primary += n;
-                else out.rays_bounce += n;
+                else if (syncEvery == 1) out.rays_bounce += n;
                 tm.nextItems = n;
                 tm.begin(0, st);
                 if (sortedNext) {   // the bounce rays in key order (kernels_sort.hip)
@@ -417,12 +435,25 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 const uint32_t gridShade = launch_shade(s->dev, dc, pool, pm, shadeQ, shadeItems, n, bounce, rp->max_bounces, rp->seed, sBase, Sp,
                                                         curPixels, sqOut, qout, pool.qS, (s->hasMicrofacet ? 1 : 0) | (s->hasPhong ? 2 : 0), st, sortRays ? pool.sortKeys : nullptr);
                 tm.end(st);
-                launch_segq_scan2(sqOut, gridShade, 1, pool.qS, gridShade, shadowMult, 256, pool.totals, st);
-                uint32_t cnt[2] = {0, 0};
-                RTX_HIP(hipMemcpyAsync(cnt, pool.totals, sizeof(cnt), hipMemcpyDeviceToHost, st));
-                RTX_HIP(hipStreamSynchronize(st));
-                // the host has synchronised the main stream: what goes to the side stream now runs after shade(k)
+                launch_segq_scan2(sqOut, gridShade, 1, pool.qS, gridShade, shadowMult, 256, pool.totals, st,
+                                  syncEvery > 1 ? pool.rayCounters + 2 : nullptr);
+                // read the counts back now? Always at the last bounce, where the paths left over must be known, and while the
+                // launches are large enough not to care; bounds that have come near the tail kernel's regime are checked too
+                const bool lastBounce = bounce + 1 >= rp->max_bounces;
+                const bool syncNow = syncEvery == 1 || lastBounce || n > (8u << 20) || (bounce + 1) % syncEvery == 0;
+                uint32_t cnt[2] = {n, (uint32_t)std::min<unsigned long long>((unsigned long long)n * shadowMult, 0xFFFFFFFFull)};   // upper bounds
+                if (syncNow) {
+                    RTX_HIP(hipMemcpyAsync(cnt, pool.totals, sizeof(cnt), hipMemcpyDeviceToHost, st));
+                    RTX_HIP(hipStreamSynchronize(st));
+                }
+                exact = syncNow;
+                // what goes to the side stream must run after shade(k): the host has just synchronised the main stream, or the
+                // side stream waits for a mark recorded behind the scan
                 const bool side = overlap && cnt[1] > 0 && cnt[0] > 0 && cnt[0] <= overlapMax;   // cnt[0] = 0: nothing to overlap with
+                if (side && !syncNow) {
+                    RTX_HIP(hipEventRecord(ph->mainMark, st));
+                    RTX_HIP(hipStreamWaitEvent(ph->sideStream, ph->mainMark, 0));
+                }
                 hipStream_t sst = side ? ph->sideStream : st;
                 if (cnt[1]) {
                     tm.nextItems = cnt[1];
@@ -437,6 +468,10 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 std::swap(qin, qout);
                 std::swap(sqIn, sqOut);
                 n = cnt[0];
+                if (lastBounce && syncEvery > 1) {
+                    handedOver += n;
+                    limitHit = true;
+                }   // alive at the bounce limit: counted by the device sum, never traced
                 if (sortRays && n >= sortMin && n > tailMax && bounce + 1 < rp->max_bounces) {
                     tm.nextItems = n;
                     tm.begin(sortKind, st);
@@ -444,7 +479,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                     tm.end(st);
                     sortedNext = true;
                 }
-                if (n > 0 && n <= tailMax && bounce + 1 < rp->max_bounces) {
+                if (exact && n > 0 && n <= tailMax && bounce + 1 < rp->max_bounces) {
                     // few paths left: one kernel walks them to their ends (tail_kernel)
                     if (sidePending) {
                         RTX_HIP(hipStreamWaitEvent(st, ph->sideDone, 0));
@@ -455,6 +490,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                     launch_tail(s->dev, s->cfg, dc, pool, pm, sqIn, qin, n, bounce + 1, rp->max_bounces, rp->seed, sBase, Sp, curPixels,
                                 (s->hasMicrofacet || s->hasPhong) ? 1 : 0, pm.n > 0 ? 1 : 0);
                     tm.end(st);
+                    if (syncEvery > 1) handedOver += n;   // their first rays are the tail kernel's (rayCounters[1])
                     n = 0;
                 }
                 if (tm.spans.size() > 2048) {
@@ -462,6 +498,14 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                     if (ph->sideStream) RTX_HIP(hipStreamSynchronize(ph->sideStream));
                     tm.flush();
                 }
+            }
+            if (syncEvery > 1 && n > 0 && !limitHit) {   // cancelled: the paths alive now were counted on the device but never traced
+                uint32_t left = n;
+                if (!exact) {
+                    RTX_HIP(hipMemcpyAsync(&left, pool.totals, sizeof(left), hipMemcpyDeviceToHost, st));
+                    RTX_HIP(hipStreamSynchronize(st));
+                }
+                handedOver += left;
             }
             if (sidePending) {   // a cancelled pass, or max_bounces reached with paths alive
                 RTX_HIP(hipStreamWaitEvent(st, ph->sideDone, 0));
@@ -494,8 +538,9 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     tm.flush();
     float total = 0.0f;
     (void)hipEventElapsedTime(&total, evTotal0, evTotal1);
-    unsigned long long rc2[2] = {0, 0};   // [0] shadow hops, [1] closest-hit rays traced inside tail_kernel
+    unsigned long long rc2[4] = {0, 0, 0, 0};   // [0] shadow hops, [1] closest-hit rays traced inside tail_kernel, [2] paths that left a shade launch alive
     RTX_HIP(hipMemcpy(rc2, pool.rayCounters, sizeof(rc2), hipMemcpyDeviceToHost));
+    if (syncEvery > 1 && !legacy) out.rays_bounce += rc2[2] - std::min(rc2[2], handedOver);   // every one of them was traced by the next extend launch, but for these
     out.rays_shadow = rc2[0];
     out.rays_extend = out.rays_primary + out.rays_bounce;   // traced by extend launches (the rest: tail / legacy kernel)
     out.rays_bounce += rc2[1];
