@@ -418,8 +418,11 @@ int rtx_photon_estimate(rtx_photons* p, int which, const float* positions, const
  * b % n == m into a full-frame film on its GPU (params->rank / world are ignored); the films are then copied to member
  * 0's GPU (hipMemcpyPeer: direct xGMI transfers from all peers at once) and merged there in member order - colour,
  * weight, counts and guides by sum, z by min - and resolved into the host arrays (any may be NULL), as rtx_render does.
- * Adaptive sampling runs per member on its own buckets. The one-process-per-GPU alternative (RCCL) is
- * raytracer_amd/distributed.py. */
+ * Adaptive sampling (spp_max > spp_min): round 1 on that static split; after every round the statistics of the pixels
+ * each member sampled are collected on member 0's GPU, the confidence-interval test (RayCaster.cpp:848-868) runs there,
+ * and the buckets that still hold unconverged pixels are dealt out again, heaviest first to the least loaded member
+ * (SURVEY.md 8e); only statistics move, accumulated colour stays in the film of the member that traced it. Sample maps
+ * are those of one GPU. The one-process-per-GPU alternative (RCCL) is raytracer_amd/distributed.py. */
 #define RTX_GROUP_MAX 16
 typedef struct rtx_group rtx_group;
 int rtx_group_create(const rtx_scene_desc* desc, const int* device_ids, int n, rtx_group** out);

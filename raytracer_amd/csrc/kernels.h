@@ -92,5 +92,7 @@ void launch_stats_clear(const PathPool& pool, uint32_t n, hipStream_t stream);
 void launch_film_resolve(const rtx_film& film, uint32_t n, int srgb, float* linear, unsigned char* rgb8, hipStream_t stream);
 // dst += srcs[0 .. nSrc) (accum, count, guides by sum; z by min); all buffers on the device of `stream`; nSrc < RTX_GROUP_MAX
 void launch_film_merge(const rtx_film& dst, const rtx_film* srcs, int nSrc, uint32_t n, hipStream_t stream);
+void launch_stats_take(float* dstSum, float* dstSum2, const float* srcSum, const float* srcSum2, const int* pixels, uint32_t n,
+                       hipStream_t stream);
 // rtx_math.h routine `fn` on device arrays (rtx_debug_math)
 void launch_math_probe(int fn, const float* x, const float* y, uint32_t n, float* out, hipStream_t stream);

@@ -156,6 +156,24 @@ void launch_film_merge(const rtx_film& dst, const rtx_film* srcs, int nSrc, uint
     hipLaunchKernelGGL(film_merge_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dst, m, n);
 }
 
+// Adaptive rounds over several GPUs (rtx_group.cpp): the statistics of the pixels one member sampled in the round just
+// finished replace the root's copies. Every listed pixel is sampled by exactly one member per round, so this is a plain
+// take, not a sum.
+__global__ void stats_take_kernel(float4* __restrict__ dstSum, float4* __restrict__ dstSum2, const float4* __restrict__ srcSum,
+                                  const float4* __restrict__ srcSum2, const int* __restrict__ pixels, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = pixels[i];
+    dstSum[p] = srcSum[p];
+    dstSum2[p] = srcSum2[p];
+}
+void launch_stats_take(float* dstSum, float* dstSum2, const float* srcSum, const float* srcSum2, const int* pixels, uint32_t n,
+                       hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(stats_take_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (float4*)dstSum, (float4*)dstSum2, (const float4*)srcSum,
+                       (const float4*)srcSum2, pixels, n);
+}
+
 void launch_median3(const float* src, int W, int H, int srgb, float* linear, unsigned char* rgb8, hipStream_t stream) {
     dim3 block(64, 4), grid((W + 63) / 64, (H + 3) / 4);
     hipLaunchKernelGGL(median3_kernel, grid, block, 0, stream, src, W, H, srgb, linear, rgb8);

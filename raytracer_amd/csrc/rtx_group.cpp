@@ -5,6 +5,7 @@
 #include "photon.h"
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -16,6 +17,10 @@ struct Member {
     rtx_photons* photons = nullptr;
     rtx_film film{};           // on `device`
     rtx_film staged{};         // copy of this member's film on member 0's device (members > 0 on another device)
+    // adaptive rounds (spp_max > spp_min, more than one member): per-pixel statistics on `device`, and for members on
+    // another device their copy on member 0's
+    rtx_pixel_stats pstats{};
+    rtx_pixel_stats pstatsStaged{};
 };
 
 struct FilmAlloc {
@@ -51,7 +56,62 @@ struct FilmAlloc {
 struct rtx_group {
     std::vector<Member> m;
     size_t filmPixels = 0;
+    size_t statPixels = 0;
+    int* listDev = nullptr;    // on member 0's device: the pixel list of one member (statPixels entries)
 };
+
+static void free_stats(rtx_pixel_stats& p) {
+    if (p.sum) (void)hipFree(p.sum);
+    if (p.sum2) (void)hipFree(p.sum2);
+    p.sum = p.sum2 = nullptr;
+}
+static int alloc_stats(rtx_pixel_stats& p, size_t n) {   // on the current device
+    if (hipMalloc((void**)&p.sum, n * 16) != hipSuccess || hipMalloc((void**)&p.sum2, n * 16) != hipSuccess) {
+        free_stats(p);
+        return rtx_fail(RTX_ERR_HIP, "group statistics allocation failed");
+    }
+    return RTX_OK;
+}
+static void release_stats(rtx_group* g) {
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (size_t i = 0; i < g->m.size(); ++i) {
+        (void)hipSetDevice(g->m[i].device);
+        free_stats(g->m[i].pstats);
+        (void)hipSetDevice(g->m[0].device);
+        free_stats(g->m[i].pstatsStaged);
+    }
+    if (!g->m.empty()) (void)hipSetDevice(g->m[0].device);
+    if (g->listDev) (void)hipFree(g->listDev);
+    g->listDev = nullptr;
+    (void)hipSetDevice(prev);
+    g->statPixels = 0;
+}
+static int ensure_stats(rtx_group* g, size_t n) {
+    if (g->statPixels == n) return RTX_OK;
+    release_stats(g);
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    int rc = RTX_OK;
+    for (size_t i = 0; i < g->m.size() && rc == RTX_OK; ++i) {
+        if (hipSetDevice(g->m[i].device) != hipSuccess) rc = rtx_fail(RTX_ERR_HIP, "hipSetDevice failed");
+        if (rc == RTX_OK) rc = alloc_stats(g->m[i].pstats, n);
+        if (rc == RTX_OK && i > 0 && g->m[i].device != g->m[0].device) {
+            if (hipSetDevice(g->m[0].device) != hipSuccess) rc = rtx_fail(RTX_ERR_HIP, "hipSetDevice failed");
+            if (rc == RTX_OK) rc = alloc_stats(g->m[i].pstatsStaged, n);
+        }
+    }
+    if (rc == RTX_OK && (hipSetDevice(g->m[0].device) != hipSuccess || hipMalloc((void**)&g->listDev, n * sizeof(int)) != hipSuccess))
+        rc = rtx_fail(RTX_ERR_HIP, "group pixel list allocation failed");
+    (void)hipSetDevice(prev);
+    if (rc != RTX_OK) {
+        const std::string msg = rtx_last_error();
+        release_stats(g);
+        return rtx_fail(rc, msg);
+    }
+    g->statPixels = n;
+    return RTX_OK;
+}
 
 // runs fn(member index) on one host thread per member, each with its member's device current; the first failure's
 // message becomes this thread's rtx_last_error
@@ -117,13 +177,158 @@ static int ensure_films(rtx_group* g, size_t n) {
     return RTX_OK;
 }
 
+static void add_stats(rtx_stats& a, const rtx_stats& s) {
+    a.rays_primary += s.rays_primary;
+    a.rays_bounce += s.rays_bounce;
+    a.rays_shadow += s.rays_shadow;
+    a.paths += s.paths;
+    a.nodes_visited += s.nodes_visited;
+    a.tris_tested += s.tris_tested;
+    a.extend_launches += s.extend_launches;
+    a.rays_extend += s.rays_extend;
+    a.extend_ms += s.extend_ms;
+    a.shadow_ms += s.shadow_ms;
+    a.shade_ms += s.shade_ms;
+    a.total_ms += s.total_ms;
+}
+
+// Greedy longest-processing-time deal of the buckets that still hold unconverged pixels: heaviest bucket first (ties by
+// bucket index) to the least loaded member (ties to the lowest member) - the same rule on every run, and the rule of
+// raytracer_amd/distributed.py::lpt_assign.
+static void lpt_assign(const std::vector<int>& weight, int members, std::vector<int>& owner) {
+    owner.assign(weight.size(), -1);
+    std::vector<int> busy;
+    for (size_t b = 0; b < weight.size(); ++b)
+        if (weight[b] > 0) busy.push_back((int)b);
+    std::stable_sort(busy.begin(), busy.end(), [&](int x, int y) { return weight[x] > weight[y]; });
+    std::vector<long long> load(members, 0);
+    for (int b : busy) {
+        int r = 0;
+        for (int k = 1; k < members; ++k)
+            if (load[k] < load[r]) r = k;
+        owner[b] = r;
+        load[r] += weight[b];
+    }
+}
+
+// Adaptive CastRays (spp_min ... spp_max, RayCaster.cpp:770-980) over the members with the work dealt out again after
+// every round: round 1 on the static split b % n; after a round the statistics of the pixels each member
+// sampled are collected on member 0's GPU, the confidence-interval test runs there, the buckets that still hold
+// unconverged pixels are dealt out by lpt_assign, and the merged statistics go back to every member (a bucket that
+// changes hands continues from the sums its previous owner left). Accumulated colour never moves: it stays in the film
+// of the member that traced it and the films are summed at frame end, as in the fixed-spp case.
+static int group_render_adaptive(rtx_group* g, const rtx_camera* cam, const rtx_render_params* params, std::vector<rtx_stats>& st) {
+    const int n = (int)g->m.size();
+    const int W = cam->width, H = cam->height;
+    const size_t np = (size_t)W * H;
+    const int tile = params->tile_size > 0 ? params->tile_size : 16;
+    int rc = ensure_stats(g, np);
+    if (rc != RTX_OK) return rc;
+    std::vector<std::vector<int>> mine(n);
+    for (int i = 0; i < n; ++i) {
+        const int64_t len = rtx_debug_pixel_list(W, H, tile, i, n, nullptr, 0);
+        if (len < 0) return (int)len;
+        std::vector<int> padded((size_t)len);
+        (void)rtx_debug_pixel_list(W, H, tile, i, n, padded.data(), padded.size());
+        for (int p : padded)
+            if (p >= 0) mine[i].push_back(p);
+    }
+    rc = for_each_member(g, [&](int i) {
+        Member& mb = g->m[i];
+        int r = rtx_film_clear(&mb.film, W, H, nullptr);
+        if (r != RTX_OK) return r;
+        RTX_HIP(hipMemset(mb.pstats.sum, 0, np * 16));
+        RTX_HIP(hipMemset(mb.pstats.sum2, 0, np * 16));
+        RTX_HIP(hipDeviceSynchronize());
+        return (int)RTX_OK;
+    });
+    if (rc != RTX_OK) return rc;
+    const int nbx = (W + tile - 1) / tile, nby = (H + tile - 1) / tile;
+    std::vector<int> refine(np), weight, owner;
+    int base = 0;
+    for (int round = 0;; ++round) {
+        const int nS = std::min(params->spp_min, params->spp_max - base);
+        if (nS <= 0) break;
+        const bool more = params->spp_max > params->spp_min && base + nS < params->spp_max;
+        rc = for_each_member(g, [&](int i) {
+            Member& mb = g->m[i];
+            rtx_stats one;
+            std::memset(&one, 0, sizeof(one));
+            if (!mine[i].empty()) {
+                const int r = rtx_render_round(mb.scene, cam, params, (params->use_photons ? mb.photons : nullptr), &mb.film, &mb.pstats,
+                                               mine[i].data(), mine[i].size(), base, nS, round == 1 ? 1 : 0, &one);
+                if (r != RTX_OK) return r;
+                add_stats(st[i], one);
+            }
+            // statistics towards member 0's device, every peer over its own link
+            if (more && i > 0 && mb.device != g->m[0].device) {
+                RTX_HIP(hipMemcpyPeer(mb.pstatsStaged.sum, g->m[0].device, mb.pstats.sum, mb.device, np * 16));
+                RTX_HIP(hipMemcpyPeer(mb.pstatsStaged.sum2, g->m[0].device, mb.pstats.sum2, mb.device, np * 16));
+            }
+            RTX_HIP(hipDeviceSynchronize());
+            return (int)RTX_OK;
+        });
+        if (rc != RTX_OK) return rc;
+        base += nS;
+        if (!more) break;
+        // ---- on member 0's device: collect, test, deal ----
+        int prev = 0;
+        (void)hipGetDevice(&prev);
+        RTX_HIP(hipSetDevice(g->m[0].device));
+        for (int i = 1; i < n; ++i) {
+            if (mine[i].empty()) continue;
+            const rtx_pixel_stats& src = g->m[i].device != g->m[0].device ? g->m[i].pstatsStaged : g->m[i].pstats;
+            RTX_HIP(hipMemcpy(g->listDev, mine[i].data(), mine[i].size() * sizeof(int), hipMemcpyHostToDevice));
+            launch_stats_take(g->m[0].pstats.sum, g->m[0].pstats.sum2, src.sum, src.sum2, g->listDev, (uint32_t)mine[i].size(), nullptr);
+            RTX_HIP(hipGetLastError());
+            RTX_HIP(hipDeviceSynchronize());   // listDev is reused by the next member
+        }
+        const int64_t nRef = rtx_refine_list(&g->m[0].pstats, W, H, params->ci_halfwidth, params->spp_max, refine.data(), refine.size());
+        (void)hipSetDevice(prev);
+        if (nRef < 0) return (int)nRef;
+        if (nRef == 0) break;
+        weight.assign((size_t)nbx * nby, 0);
+        for (int64_t k = 0; k < nRef; ++k) weight[(size_t)((refine[k] / W) / tile) * nbx + (refine[k] % W) / tile]++;
+        lpt_assign(weight, n, owner);
+        for (int i = 0; i < n; ++i) mine[i].clear();
+        for (int64_t k = 0; k < nRef; ++k) mine[owner[(size_t)((refine[k] / W) / tile) * nbx + (refine[k] % W) / tile]].push_back(refine[k]);
+        // ---- the merged statistics back to the members ----
+        rc = for_each_member(g, [&](int i) {
+            Member& mb = g->m[i];
+            if (i == 0 || mine[i].empty()) return (int)RTX_OK;
+            if (mb.device != g->m[0].device) {
+                RTX_HIP(hipMemcpyPeer(mb.pstats.sum, mb.device, g->m[0].pstats.sum, g->m[0].device, np * 16));
+                RTX_HIP(hipMemcpyPeer(mb.pstats.sum2, mb.device, g->m[0].pstats.sum2, g->m[0].device, np * 16));
+            } else {
+                RTX_HIP(hipMemcpy(mb.pstats.sum, g->m[0].pstats.sum, np * 16, hipMemcpyDeviceToDevice));
+                RTX_HIP(hipMemcpy(mb.pstats.sum2, g->m[0].pstats.sum2, np * 16, hipMemcpyDeviceToDevice));
+            }
+            RTX_HIP(hipDeviceSynchronize());
+            return (int)RTX_OK;
+        });
+        if (rc != RTX_OK) return rc;
+    }
+    // films towards member 0's device
+    return for_each_member(g, [&](int i) {
+        Member& mb = g->m[i];
+        if (i > 0 && mb.device != g->m[0].device)
+            for (int k = 0; k < 5; ++k)
+                RTX_HIP(hipMemcpyPeer(*FilmAlloc::slot(mb.staged, k), g->m[0].device, *FilmAlloc::slot(mb.film, k), mb.device, FilmAlloc::bytes(k, np)));
+        RTX_HIP(hipDeviceSynchronize());
+        return (int)RTX_OK;
+    });
+}
+
 extern "C" {
 
 void rtx_group_destroy(rtx_group* g) {
     if (!g) return;
     int prev = 0;
     (void)hipGetDevice(&prev);
-    if (!g->m.empty()) release_films(g);
+    if (!g->m.empty()) {
+        release_films(g);
+        release_stats(g);
+    }
     for (Member& mb : g->m) {
         (void)hipSetDevice(mb.device);
         rtx_photons_destroy(mb.photons);
@@ -175,7 +380,9 @@ int rtx_group_render(rtx_group* g, const rtx_camera* cam, const rtx_render_param
     if (rc != RTX_OK) return rc;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<rtx_stats> st(n);
-    rc = for_each_member(g, [&](int i) {
+    for (rtx_stats& x : st) std::memset(&x, 0, sizeof(x));
+    const bool rebalance = n > 1 && params->spp_max > params->spp_min && !std::getenv("RTX_AMD_GROUP_STATIC");
+    rc = rebalance ? group_render_adaptive(g, cam, params, st) : for_each_member(g, [&](int i) {
         Member& mb = g->m[i];
         rtx_render_params rp = *params;
         rp.rank = i;

@@ -95,7 +95,7 @@ def group_env(rtx):
 
 
 @pytest.mark.parametrize("members", [1, 2, 3])
-def test_group_render_equals_single_device(group_env, rtx, members):
+def test_group_render_equals_single_device(group_env, rtx, members, monkeypatch):
     from raytracer_amd.scene import render_params
     sd, gs, cam = group_env
     grp = rtx.Group(sd, [0] * members)
@@ -118,11 +118,21 @@ def test_group_render_equals_single_device(group_env, rtx, members):
     gs.render_accumulate(cam, rp, f)
     one = rtx.film_resolve(f, cam, want_aov=True)
     assert np.array_equal(got["albedo"], one["albedo"]) and np.array_equal(got["normal"], one["normal"])
-    # adaptive sampling per member on its own buckets: a pixel's decision uses only its own samples, so the maps agree
-    rpa = render_params(spp_min=8, spp_max=32, max_bounces=8, ci_halfwidth=0.02)
+    # adaptive sampling: after every round the unconverged buckets are dealt out again over the members (statistics
+    # collected on member 0, greedy LPT, merged statistics back: rtx_group.cpp). A pixel's decision uses only its own
+    # samples, whoever traced them, so the sample maps are those of one GPU - and of the static split.
+    rpa = render_params(spp_min=8, spp_max=40, max_bounces=8, ci_halfwidth=0.02)
     a, b = grp.render(cam, rpa), gs.render(cam, rpa)
-    assert np.array_equal(a["samples"], b["samples"]) and (a["samples"] > 8).any()
+    assert np.array_equal(a["samples"], b["samples"]) and (a["samples"] > 16).any() and (a["samples"] == 8).any()
+    assert np.array_equal(a["z"], b["z"])
     assert np.allclose(a["linear"], b["linear"], rtol=2e-4, atol=2e-5)
+    for k in ("rays_primary", "rays_bounce", "rays_shadow", "paths"):
+        assert a["stats"][k] == b["stats"][k], k
+    monkeypatch.setenv("RTX_AMD_GROUP_STATIC", "1")
+    c = grp.render(cam, rpa)
+    monkeypatch.delenv("RTX_AMD_GROUP_STATIC")
+    assert np.array_equal(c["samples"], b["samples"])
+    assert np.allclose(c["linear"], b["linear"], rtol=2e-4, atol=2e-5)
     grp.close()
 
 
