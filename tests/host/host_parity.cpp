@@ -514,7 +514,32 @@ int main() {
             dP = std::max(dP, (double)std::max(std::fabs(a.r - b.r), std::max(std::fabs(a.g - b.g), std::fabs(a.b - b.b))) / (1.0 + b.r + b.g + b.b));
         }
         CHECK(dP < 1e-3, "group CastRays with photons vs single device: max relative difference %.2e", dP);
+        // adaptive frame (8 ... 32 samples): the members deal the unconverged buckets out again after every round
+        // (rtx_group.cpp); the sample map must be the single device's
+        rg.sampling.minSamples = 8;
+        rg.sampling.maxSamples = 32;
+        rg.sampling.maxHalfWidth = 0.02f;
+        RenderImage imgGA;
+        imgGA.Init(cam.imgWidth, cam.imgHeight);
+        rg.CastRays(imgGA);
         g_rtDevices.clear();
+        ReleaseGpuScenes();
+        RayCaster r1(&scene, &cam);
+        r1.sampling = rg.sampling;
+        r1.sampling.devices.clear();
+        RenderImage img1A;
+        img1A.Init(cam.imgWidth, cam.imgHeight);
+        r1.CastRays(img1A);
+        int badA = 0, refined = 0;
+        double dA = 0;
+        for (size_t i = 0; i < np; ++i) {
+            const Color &a = imgGA.GetLinearPixels()[i], &b = img1A.GetLinearPixels()[i];
+            dA = std::max(dA, (double)std::max(std::fabs(a.r - b.r), std::max(std::fabs(a.g - b.g), std::fabs(a.b - b.b))) / (1.0 + b.r + b.g + b.b));
+            if (imgGA.GetSampleCount()[i] != img1A.GetSampleCount()[i]) ++badA;
+            if (img1A.GetSampleCount()[i] > 8) ++refined;
+        }
+        CHECK(badA == 0 && refined > 0 && dA < 2e-4, "adaptive group CastRays vs single device: %d sample counts differ, %d pixels refined, max relative colour difference %.2e",
+              badA, refined, dA);
         ReleaseGpuScenes();
     }
 
