@@ -4,22 +4,25 @@
 // ShadeInfoAdapter (RayTracer/ShadeInfoAdapter.h:49-231).
 //
 // The reference evaluates a recursion tree per camera sample: every Shade() may call TraceSecondaryRay up to three
-// times (diffuse bounce, glossy reflection, glossy refraction), at most 5 levels deep (CanBounce, :44). The tree is
-// LINEAR in the colours its calls return - every use is `colour * weight` with a weight known at the call, and the
-// Beer-Lambert factor of a refraction ray (:359) needs only that ray's own hit distance - so it is evaluated here
-// without recursion: a pending call is a record {biased ray, weight of its colour in the sample, absorption, RNG node,
-// depth}; one lane per camera sample keeps such records on a small private stack, and legacy_kernel runs the lanes of a
-// wave as state machines that share their traversal and shading steps (see there). Sums are formed in a different order
-// than the recursion's (parity with the oracle is a tolerance, as for the path mode).
+// times (diffuse bounce, glossy reflection, glossy refraction), at most 5 levels deep (CanBounce, :44), and one
+// TraceShadowRay per light. Here a lane evaluates the tree without recursion but in the reference's own order and
+// with its own arithmetic: an open Shade() is a FRAME (LgFrame: the running `local`, the factors its children's colours
+// will be multiplied by, where its result goes), the rays it still has to trace are CALLS on a small private stack
+// (LgCall: a secondary ray, or the shadow query of one light with that light's terms of `local`), pushed in reverse so
+// that they are traced as the recursion would - lights in order, diffuse bounce, reflection, refraction - and a frame is
+// closed (its result formed exactly as Shade() returns it, and handed to the frame below) when the stack is back at the
+// height it was opened at. legacy_kernel runs the lanes of a wave as state machines that share their traversal and
+// shading steps (see there). Per-sample radiance is the oracle's bit for bit.
 //
 // Random numbers: Shade() number `node` of the tree (root 0; children 3*node+1 diffuse, +2 reflection, +3 refraction)
 // draws from the counter generator keyed (pixel, sample) x node x draw slot, identically in oracle/oracle_legacy.cpp.
 #include "shade_body.h"
 
 #define LG_MAX_BOUNCES 5        // ShadeInfoAdapter::kMaxSpecularBounces (:245)
+#define LG_FRAMES (LG_MAX_BOUNCES + 1)   // Shade() calls open at once: bounce 0 .. 5
 #define LG_STACK 20             // 3 calls at depth 0, then 2 left + 3 new per level down to depth 4: 11; + one queued
-                                // shadow query per light (<= 8) of the Shade() just evaluated (legacy_kernel)
-#define LG_SHADOW_CALL 0x80000000u   // LgCall::bounceDepth of a queued TraceShadowRay query
+                                // shadow query per light (<= 8) of the Shade() just opened
+#define LG_SHADOW_CALL 0x80000000u   // LgCall::kind of a queued TraceShadowRay query (bit 0: the light has a second term)
 #define LG_DIM_REFL 32          // draw slots of SampleGlossy for the reflection / refraction ray
 #define LG_DIM_REFR 34
 #ifndef LG_BATCH
@@ -31,18 +34,54 @@
 #define LG_LEAF_WEIGHT 1u
 #endif
 
-struct LgCall {                 // one pending TraceSecondaryRay call
-    f3 o, d;                    // biased origin, unit direction (:99-112)
-    f3 w;                       // weight of the returned colour in the sample's radiance
-    f3 absorb;                  // Beer-Lambert coefficients applied over the call's `dist` (refraction rays), else 0
-    uint32_t node;              // RNG node of the Shade() the call leads to
-    uint32_t bounceDepth;       // bounce of that Shade() | diffuse depth of the caller << 8
+struct LgCall {                 // one pending TraceSecondaryRay call or TraceShadowRay query
+    f3 o, d;                    // biased origin, unit direction (:99-112 / :57-70)
+    f3 a, b;                    // secondary ray: a = Beer-Lambert coefficients over the call's `dist` (refraction rays), else 0
+                                // shadow query: the light's terms of `local`, added in this order if nothing blocks
+    float selfDist, limit;      // shadow query: hits of the receiver closer than selfDist are ignored; blocked before `limit`
+                                // (< 0: unbounded segment; -2: TraceShadowRay returns 1 whatever is hit)
+    uint32_t node;              // secondary ray: RNG node of the Shade() the call leads to; shadow query: the receiver's object
+    uint32_t kind;              // secondary ray: bounce of that Shade() | diffuse depth of the caller << 8 | slot << 16
+                                // (1 diffuse, 2 reflection, 3 refraction: where the colour goes in the caller's frame)
+};
+
+#define LG_F_SLOT 3u            // frame flags: slot of the frame below that receives the result (0: the sample itself)
+#define LG_F_MICRO 4u
+#define LG_F_SPAWN 8u
+#define LG_F_DIEL 16u
+#define LG_F_INDIRECT 32u       // the fields below hold something (else they were never written and read as zero / one)
+#define LG_F_CAUSTIC 64u
+#define LG_F_EMISSION 128u
+#define LG_F_FACTOR 256u
+#define LG_F_REFLC 512u
+#define LG_F_REFRC 1024u
+// One open Shade(). The frame is written and read field by field, and only the fields a Shade() needs (a diffuse
+// surface: diffMult, diffProb, indirect): the frames and the call stack live in scratch memory, 2.4 KB per lane that no
+// cache holds for a whole grid, and the kernel's time follows that traffic.
+struct LgFrame {
+    f3 local;                   // `local` so far (microfacet: `result`), base, flags: valid while a deeper frame is open
+    uint32_t base;              //   (the innermost frame's copies are LgState::topLocal / topBase / topFlags)
+    uint32_t flags;
+    f3 diffMult;                // diffuse bounce: indirect = colour * diffMult / diffProb (microfacet: colour * diffMult)
+    float diffProb;
+    f3 indirect;                // global-map term, or the diffuse bounce once its colour is in (:419-457)
+    f3 caustic;
+    f3 oneMinusRefl, reflMul, refrMul;   // :499-507
+    f3 reflC, refrC;            // colours of the reflection / refraction call
+    f3 emission;
+    f3 retFactor;               // Beer-Lambert factor on the result (a refraction call's hit, :359)
 };
 
 struct LgState {
-    f3 L;
-    uint32_t sp, rays, shadows;
+    f3 L;                       // the sample's radiance once the root frame has closed
+    uint32_t sp, fp, rays, shadows;
+    // the innermost open frame's running sum, base and flags live here, in registers: three of four returning calls are
+    // shadow queries, which then touch no memory at all
+    f3 topLocal;
+    uint32_t topBase;           // height of the call stack when the frame was opened
+    uint32_t topFlags;
     LgCall stack[LG_STACK];
+    LgFrame frames[LG_FRAMES];
 };
 
 // PLAIN: Blinn materials only and no photon maps in this call (launch_legacy decides): the Phong and microfacet forms of
@@ -85,93 +124,17 @@ __device__ __forceinline__ float lg_light_intersect(const DevLight& L, f3 o, f3 
     return t0;
 }
 
-// ShadeInfoAdapter::TraceShadowRay (:49-88): one closest hit from the biased origin; the receiver's own node is
-// ignored close to the origin, a finite segment is blocked only before the light.
-template <class G>
-__device__ __forceinline__ float lg_trace_shadow(const G& g, const SampCtx& sx, int obj, f3 dir, float tMax, LgState& S) {
-    const float Llen = len3(dir);
-    if (Llen < 1e-12f) return 1.0f;
-    const bool finiteSegment = tMax < RTX_BIG * 0.5f;
-    const float segLenWorld = finiteSegment ? Llen * tMax : RTX_BIG;
-    const f3 Ldir = dir / Llen;
-    const f3 N = sx.N;
-    const float nDotL = dot3(N, Ldir);
-    const float baseBias = 1e-4f;
-    const float nBias = baseBias * (1.0f + 2.0f * (1.0f - fabsf(nDotL)));
-    const float dBias = baseBias * 0.5f;
-    const f3 o = sx.P + ((nDotL >= 0.0f) ? N : -N) * nBias + Ldir * dBias;
-    const RayT r{o.x, o.y, o.z, Ldir.x, Ldir.y, Ldir.z, RTX_BIG};
-    uint32_t nc = 0, tc = 0;
-    S.shadows++;
-    const HitT h = traverse_closest<false>(g.sc, r, RTX_HIT_FRONT_AND_BACK, g.st, &nc, &tc);
-    if (h.slot < 0) return 1.0f;
-    f3 GN;
-    bool front;
-    int hobj;
-    triangle_gn(g.sc, r, h.slot, h.t, GN, front, hobj);
-    const float4 b = reinterpret_cast<const float4*>(g.sc.tris)[(size_t)h.slot * 3 + 1];
-    f3 hp = o + Ldir * h.t;
-    if (__float_as_uint(b.w) != 0u) {   // Sphere / Plane: the hit point comes back through the node transform
-        SurfHit sh;
-        resolve_triangle(g.sc, r, h, sh);
-        hp = sh.p;
-    }
-    const float dist = len3(hp - o);
-    if (hobj == obj && dist < (nBias + dBias) * 6.0f) return 1.0f;
-    if (!finiteSegment) return dist > 0.0f ? 0.0f : 1.0f;
-    const float allowance = nBias * 1.5f;
-    return (dist < segLenWorld - allowance) ? 0.0f : 1.0f;
-}
-
-// PointLight::Illuminate (Shading_Legacy.cpp:115-210). TraceShadowRay returns exactly 0 or 1, so the first cone sample
-// is always "unanimous" (:189) and the 2nd..4th samples of the adaptive loop are never taken: one shadow ray per light.
-template <class G>
-__device__ __forceinline__ f3 lg_illuminate(const G& g, const SampCtx& sx, int obj, const DevLight& light, int l, f3& dir, LgState& S) {
-    const f3 toC = ld3(light.pos) - sx.P;
-    const float distC = len3(toC);
-    if (distC < 1e-20f) {
-        dir = mk3(0.0f);
-        return mk3(0.0f);
-    }
-    const f3 L = toC / distC;
-    dir = L;
-    float atten = 1.0f;
-    if (light.attenuation > 0.0f) atten = 1.0f / ((light.attenuation * distC) * (light.attenuation * distC));
-    const f3 I = ld3(light.intensity);
-    if (light.size <= 0.0f) return I * lg_trace_shadow(g, sx, obj, toC, 1.0f, S) * atten;
-    f3 U, V;
-    build_onb(L, U, V);
-    const float jx = sx.rnd(DIM_LIGHT0 + 2 * l), jy = sx.rnd(DIM_LIGHT0 + 2 * l + 1);
-    float h2 = 0.5f + jx;                 // Halton(1, 2)
-    h2 -= floorf(h2);
-    float h3 = (1.0f / 3.0f) * 1.0f + jy;   // Halton(1, 3)
-    h3 -= floorf(h3);
-    const float gamma = rtx_asinf(light.size / distC);
-    const float cosTheta = 1.0f - h2 * (1.0f - rtx_cosf(gamma));
-    const float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
-    const float phi = 2.0f * PI_F * h3;
-    const f3 sampleDir = normalized3(U * rtx_cosf(phi) * sinTheta + V * rtx_sinf(phi) * sinTheta + L * cosTheta);
-    const float vis = lg_trace_shadow(g, sx, obj, sampleDir * distC, 1.0f, S);
-    const float avgVis = vis / 1.0f;
-    return I * avgVis * atten;
-}
-
-// ---- the same two functions with the traversal taken out (legacy_kernel): the shadow segment becomes a queued call
-// that carries the light's whole contribution as its weight - visibility is exactly 0 or 1 - and is traced by the
-// kernel's shared traversal loop; lg_shadow_visible decides it from the closest hit as lg_trace_shadow does.
-// The record reuses LgCall: absorb.x = self-hit distance, absorb.y = blocking limit (< 0: unbounded segment),
-// node = the receiver's object, bounceDepth = LG_SHADOW_CALL.
-__device__ __forceinline__ void lg_push_shadow(const SampCtx& sx, int obj, f3 dir, float tMax, f3 w, LgState& S) {
-    if (w.x == 0.0f && w.y == 0.0f && w.z == 0.0f) return;
-    const float Llen = len3(dir);
-    if (Llen < 1e-12f) {   // TraceShadowRay returns 1 without tracing
-        S.L = S.L + w;
-        return;
-    }
+// ShadeInfoAdapter::TraceShadowRay (:49-88) as a queued call: one closest hit from the biased origin, traced by the
+// shared traversal loop; lg_shadow_visible decides it from that hit - the receiver's own node is ignored close to the
+// origin, a finite segment is blocked only before the light. The result is exactly 0 or 1, so the query carries the
+// light's terms of `local` (t1, then t2 if hasT2) and they are added to the open frame if nothing blocks.
+__device__ __forceinline__ void lg_push_shadow(const SampCtx& sx, int obj, f3 dir, float tMax, f3 t1, f3 t2, bool hasT2, LgState& S) {
     if (S.sp >= LG_STACK) return;   // cannot happen (see LG_STACK)
+    const float Llen = len3(dir);
+    const bool always = Llen < 1e-12f;   // TraceShadowRay returns 1 without tracing; kept in the queue for the order of the sums
     const bool finiteSegment = tMax < RTX_BIG * 0.5f;
     const float segLenWorld = finiteSegment ? Llen * tMax : RTX_BIG;
-    const f3 Ldir = dir / Llen;
+    const f3 Ldir = always ? mk3(0.0f, 1.0f, 0.0f) : dir / Llen;
     const f3 N = sx.N;
     const float nDotL = dot3(N, Ldir);
     const float baseBias = 1e-4f;
@@ -180,13 +143,17 @@ __device__ __forceinline__ void lg_push_shadow(const SampCtx& sx, int obj, f3 di
     LgCall& c = S.stack[S.sp++];
     c.o = sx.P + ((nDotL >= 0.0f) ? N : -N) * nBias + Ldir * dBias;
     c.d = Ldir;
-    c.w = w;
-    c.absorb = mk3((nBias + dBias) * 6.0f, finiteSegment ? segLenWorld - nBias * 1.5f : -1.0f, 0.0f);
+    c.a = t1;
+    c.b = t2;
+    c.selfDist = (nBias + dBias) * 6.0f;
+    c.limit = always ? -2.0f : (finiteSegment ? segLenWorld - nBias * 1.5f : -1.0f);
     c.node = (uint32_t)obj;
-    c.bounceDepth = LG_SHADOW_CALL;
+    c.kind = LG_SHADOW_CALL | (hasT2 ? 1u : 0u);
     S.shadows++;
 }
-__device__ __forceinline__ bool lg_shadow_visible(const DevScene& sc, const LgCall& c, const HitT& h) {
+template <class SC>
+__device__ __forceinline__ bool lg_shadow_visible(const SC& sc, const LgCall& c, const HitT& h) {
+    if (c.limit == -2.0f) return true;
     if (h.slot < 0) return true;
     const RayT r{c.o.x, c.o.y, c.o.z, c.d.x, c.d.y, c.d.z, RTX_BIG};
     f3 GN;
@@ -201,22 +168,24 @@ __device__ __forceinline__ bool lg_shadow_visible(const DevScene& sc, const LgCa
         hp = sh.p;
     }
     const float dist = len3(hp - c.o);
-    if (hobj == (int)c.node && dist < c.absorb.x) return true;
-    if (c.absorb.y < 0.0f) return !(dist > 0.0f);
-    return !(dist < c.absorb.y);
+    if (hobj == (int)c.node && dist < c.selfDist) return true;
+    if (c.limit < 0.0f) return !(dist > 0.0f);
+    return !(dist < c.limit);
 }
-// Illuminate with the shadow query queued: `per` is the weight of the light's radiance Li in the sample (Li = I * vis * atten)
-__device__ __forceinline__ void lg_illuminate_deferred(const SampCtx& sx, int obj, const DevLight& light, int l, f3 per, LgState& S) {
+// PointLight::Illuminate (Shading_Legacy.cpp:115-210) with the shadow query queued. TraceShadowRay returns exactly 0 or
+// 1, so the first cone sample is always "unanimous" (:189) and the 2nd..4th samples of the adaptive loop are never taken:
+// one shadow ray per light, and Li = I * 1 * atten if it arrives. Returns false when Li is zero without a query.
+__device__ __forceinline__ bool lg_illuminate_deferred(const SampCtx& sx, const DevLight& light, int l, f3& Li, f3& shadowDir) {
     const f3 toC = ld3(light.pos) - sx.P;
     const float distC = len3(toC);
-    if (distC < 1e-20f) return;
+    if (distC < 1e-20f) return false;
     const f3 L = toC / distC;
     float atten = 1.0f;
     if (light.attenuation > 0.0f) atten = 1.0f / ((light.attenuation * distC) * (light.attenuation * distC));
-    const f3 w = per * (ld3(light.intensity) * atten);
+    Li = ld3(light.intensity) * 1.0f * atten;
     if (light.size <= 0.0f) {
-        lg_push_shadow(sx, obj, toC, 1.0f, w, S);
-        return;
+        shadowDir = toC;
+        return true;
     }
     f3 U, V;
     build_onb(L, U, V);
@@ -230,7 +199,8 @@ __device__ __forceinline__ void lg_illuminate_deferred(const SampCtx& sx, int ob
     const float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
     const float phi = 2.0f * PI_F * h3;
     const f3 sampleDir = normalized3(U * rtx_cosf(phi) * sinTheta + V * rtx_sinf(phi) * sinTheta + L * cosTheta);
-    lg_push_shadow(sx, obj, sampleDir * distC, 1.0f, w, S);
+    shadowDir = sampleDir * distC;
+    return true;
 }
 
 // FresnelExact (Shading_Legacy.cpp:296-318)
@@ -250,11 +220,10 @@ __device__ __forceinline__ float lg_fresnel_exact(f3 I, f3 N, float ior) {
     return clamp01f(0.5f * (Rs * Rs + Rp * Rp));
 }
 
-// The ray of a TraceSecondaryRay call (ShadeInfoAdapter.h:99-112) queued with the weight of its colour
-__device__ __forceinline__ void lg_push(LgState& S, const SampCtx& sx, f3 dir, f3 w, f3 absorb, uint32_t node, int bounce, int diffuseDepth) {
+// The ray of a TraceSecondaryRay call (ShadeInfoAdapter.h:99-112), queued; slot: where its colour goes in the open frame
+__device__ __forceinline__ void lg_push(LgState& S, const SampCtx& sx, f3 dir, f3 absorb, uint32_t node, int bounce, int diffuseDepth, uint32_t slot) {
     const float dlen = len3(dir);
-    if (dlen < 1e-20f) return;
-    if (w.x == 0.0f && w.y == 0.0f && w.z == 0.0f) return;   // its colour is multiplied by zero
+    if (dlen < 1e-20f) return;                                 // the call returns black: the slot keeps its zero
     if (S.sp >= LG_STACK) return;                              // cannot happen (see LG_STACK)
     dir = dir / dlen;
     const f3 N = sx.N;
@@ -265,10 +234,62 @@ __device__ __forceinline__ void lg_push(LgState& S, const SampCtx& sx, f3 dir, f
     LgCall& c = S.stack[S.sp++];
     c.o = sx.P + ((nDotD >= 0.0f) ? N : -N) * nBias + dir * dBias;
     c.d = dir;
-    c.w = w;
-    c.absorb = absorb;
+    c.a = absorb;   // b, selfDist, limit: shadow queries only
     c.node = node;
-    c.bounceDepth = (uint32_t)bounce | ((uint32_t)diffuseDepth << 8);
+    c.kind = (uint32_t)bounce | ((uint32_t)diffuseDepth << 8) | (slot << 16);
+}
+
+// a colour arrives in slot `slot` of the innermost frame (no frame: it is the answer itself)
+__device__ __forceinline__ void lg_deliver(LgState& S, uint32_t slot, f3 col) {
+    if (S.fp == 0u) {
+        S.L = col;
+        return;
+    }
+    LgFrame& F = S.frames[S.fp - 1u];
+    if (slot == 1u) {
+        F.indirect = (S.topFlags & LG_F_MICRO) ? col * F.diffMult : col * F.diffMult / F.diffProb;   // :689 / :443
+        S.topFlags |= LG_F_INDIRECT;
+    } else if (slot == 2u) {
+        F.reflC = col;
+        S.topFlags |= LG_F_REFLC;
+    } else {
+        F.refrC = col;
+        S.topFlags |= LG_F_REFRC;
+    }
+}
+// frames whose calls have all returned are closed, innermost first: Shade()'s result (:446-447, :499-512 / :690-692).
+// Fields that were never written enter as the zeros (retFactor: the one) the reference computes with there.
+__device__ __forceinline__ void lg_unwind(LgState& S) {
+    while (S.fp > 0u && S.sp == S.topBase) {
+        const LgFrame& F = S.frames[S.fp - 1u];
+        const uint32_t fl = S.topFlags;
+        // the frame below becomes the innermost one again: its fields are fetched together with F's
+        const uint32_t below = S.fp >= 2u ? S.fp - 2u : 0u;
+        const f3 belowLocal = S.frames[below].local;
+        const uint32_t belowBase = S.frames[below].base, belowFlags = S.frames[below].flags;
+        const f3 zero = mk3(0.0f);
+        const f3 ind = (fl & LG_F_INDIRECT) ? F.indirect : zero;
+        f3 result;
+        if (fl & LG_F_MICRO) {
+            result = S.topLocal + ind;
+        } else {
+            const f3 indirect = ind + ((fl & LG_F_CAUSTIC) ? F.caustic : zero);
+            const f3 local = S.topLocal + indirect;
+            result = local;
+            if (fl & LG_F_SPAWN) {
+                const f3 reflC = (fl & LG_F_REFLC) ? F.reflC : zero;
+                if (fl & LG_F_DIEL) result = local * F.oneMinusRefl + reflC * F.reflMul + ((fl & LG_F_REFRC) ? F.refrC : zero) * F.refrMul;
+                else result = local + reflC * F.reflMul;
+            }
+        }
+        result = result + ((fl & LG_F_EMISSION) ? F.emission : zero);
+        const f3 out = result * ((fl & LG_F_FACTOR) ? F.retFactor : mk3(1.0f));
+        --S.fp;
+        S.topLocal = belowLocal;
+        S.topBase = belowBase;
+        S.topFlags = belowFlags;
+        lg_deliver(S, fl & LG_F_SLOT, out);
+    }
 }
 
 // direction of SampleGlossy (Shading_Legacy.cpp:332-356), glossySamples = 1
@@ -370,44 +391,59 @@ __device__ __forceinline__ bool lg_generate_sample(const DevScene& sc, const Dev
     return true;
 }
 
-// One Shade() (Shading_Legacy.cpp:366-514 Blinn, :517-659 Phong, :662-694 microfacet) whose result enters the sample
-// with weight w: adds w x (its own terms) to S.L and queues its TraceSecondaryRay calls.
-// DEFER: the shadow queries of the lights are queued (lg_push_shadow) instead of traced here.
-template <bool DEFER, class G>
-__device__ __forceinline__ void lg_shade(const G& g, const DevMaterial& m, const SampCtx& sx, int obj, f3 w, int bounce,
-                                         int diffuseDepth, LgState& S) {
+// Opens the frame of one Shade() (Shading_Legacy.cpp:366-514 Blinn, :517-659 Phong, :662-694 microfacet) and queues its
+// calls, last first: refraction, reflection, diffuse bounce, then the lights from the last to the first.
+template <class G>
+__device__ __forceinline__ void lg_shade(const G& g, const DevMaterial& m, const SampCtx& sx, int obj, uint32_t retSlot, f3 retFactor,
+                                         int bounce, int diffuseDepth, LgState& S) {
     const auto& sc = g.sc;
     const bool canBounce = bounce < LG_MAX_BOUNCES;
     const uint32_t node = sx.stream;
+    if (S.fp >= (uint32_t)LG_FRAMES) return;   // cannot happen: a frame per bounce level
+    if (S.fp > 0u) {   // the frame that stops being the innermost one gets its registers back
+        LgFrame& P = S.frames[S.fp - 1u];
+        P.local = S.topLocal;
+        P.base = S.topBase;
+        P.flags = S.topFlags;
+    }
+    LgFrame& F = S.frames[S.fp++];
+    S.topLocal = mk3(0.0f);
+    S.topBase = S.sp;
+    uint32_t fl = retSlot;
+    if (!(retFactor.x == 1.0f && retFactor.y == 1.0f && retFactor.z == 1.0f)) {
+        F.retFactor = retFactor;
+        fl |= LG_F_FACTOR;
+    }
+    const f3 emission = eval_tc(sc, m.ke, m.ke_tex, sx.uvw);
+    if (!(emission.x == 0.0f && emission.y == 0.0f && emission.z == 0.0f)) {
+        F.emission = emission;
+        fl |= LG_F_EMISSION;
+    }
     if (!G::kPlain && m.type == RTX_MTL_MICROFACET) {
+        fl |= LG_F_MICRO;
         const f3 N = normalized3(sx.N);
         const f3 base = eval_tc(sc, m.kd, m.kd_tex, sx.uvw);
-        f3 result = mk3(0.0f);
-        if (bounce == 0 && !DEFER) {
-            for (int l = 0; l < sc.n_lights; ++l) {
-                const f3 Ldir = normalized3(normalized3(ld3(sc.lights[l].pos) - sx.P));   // Illuminate's dir, then Ldir.Normalize() (:672)
-                const float NdotL = fmaxf(0.0f, dot3(N, Ldir));
-                if (!(NdotL > 0.0f)) continue;   // Illuminate's result would be multiplied by nothing
-                f3 unused;
-                const f3 Li = lg_illuminate(g, sx, obj, sc.lights[l], l, unused, S);
-                result = result + base * Li * NdotL;
-            }
-        }
         if (max3c(base) > 1e-6f && canBounce) {
             f3 indirDir;
             DirInfo si;
-            if (lg_generate_sample<G::kPlain>(sc, m, sx, indirDir, si)) lg_push(S, sx, indirDir, w * si.mult, mk3(0.0f), node * 3u + 1u, bounce + 1, diffuseDepth);
-        }
-        if (bounce == 0 && DEFER) {   // queued last = traced first: the stack never holds the shadow queries of two Shade() calls
-            for (int l = 0; l < sc.n_lights; ++l) {
-                const f3 Ldir = normalized3(normalized3(ld3(sc.lights[l].pos) - sx.P));
-                const float NdotL = fmaxf(0.0f, dot3(N, Ldir));
-                if (!(NdotL > 0.0f)) continue;
-                lg_illuminate_deferred(sx, obj, sc.lights[l], l, w * (base * NdotL), S);
+            if (lg_generate_sample<G::kPlain>(sc, m, sx, indirDir, si) && !(si.mult.x == 0.0f && si.mult.y == 0.0f && si.mult.z == 0.0f)) {
+                F.diffMult = si.mult;
+                lg_push(S, sx, indirDir, mk3(0.0f), node * 3u + 1u, bounce + 1, diffuseDepth, 1u);
             }
         }
-        result = result + eval_tc(sc, m.ke, m.ke_tex, sx.uvw);
-        S.L = S.L + w * result;
+        S.topFlags = fl;
+        if (bounce == 0) {
+            for (int l = sc.n_lights - 1; l >= 0; --l) {
+                const f3 Ldir = normalized3(normalized3(ld3(sc.lights[l].pos) - sx.P));   // Illuminate's dir, then Ldir.Normalize() (:672)
+                const float NdotL = fmaxf(0.0f, dot3(N, Ldir));
+                if (!(NdotL > 0.0f)) continue;   // Illuminate's result would be multiplied by nothing
+                f3 Li, sdir;
+                if (!lg_illuminate_deferred(sx, sc.lights[l], l, Li, sdir)) continue;
+                const f3 t1 = base * Li * NdotL;
+                if (t1.x == 0.0f && t1.y == 0.0f && t1.z == 0.0f) continue;
+                lg_push_shadow(sx, obj, sdir, 1.0f, t1, mk3(0.0f), false, S);
+            }
+        }
         return;
     }
     const bool phong = !G::kPlain && m.type == RTX_MTL_PHONG;
@@ -418,60 +454,21 @@ __device__ __forceinline__ void lg_shade(const G& g, const DevMaterial& m, const
     const float alpha = eval_tf(sc, m.gloss, m.gloss_tex, sx.uvw);
     const f3 kd = eval_tc(sc, m.kd, m.kd_tex, sx.uvw);
     const f3 ks = eval_tc(sc, m.ks, m.ks_tex, sx.uvw);
-
-    // reflection / refraction decide the weight of `local` (:499-507), so they come first here
     const f3 refl = eval_tc(sc, m.kr, m.kr_tex, sx.uvw);
     const f3 refrRaw = eval_tc(sc, m.kt, m.kt_tex, sx.uvw);
     const bool isDielectric = max3c(refrRaw) > 1e-6f;
     const bool spawn = (isDielectric || max3c(refl) > 1e-4f) && canBounce;
-    const f3 wLocal = (spawn && isDielectric) ? w * (mk3(1.0f) - refl) : w;
 
-    // direct light (USE_PHOTON_MAP_DIRECT = false)
-    f3 local = mk3(0.0f);
-    for (int l = 0; l < (DEFER ? 0 : sc.n_lights); ++l) {
-        const DevLight& light = sc.lights[l];
-        const f3 Ldir = normalized3(normalized3(ld3(light.pos) - sx.P));   // Illuminate's dir, then Ldir.Normalize() (:408)
-        const float NdotL = fmaxf(0.0f, dot3(N, Ldir));
-        if (!(NdotL > 0.0f)) continue;   // the reference calls Illuminate first and drops its result here (:406-410)
-        f3 unused;
-        const f3 Li = lg_illuminate(g, sx, obj, light, l, unused, S);
-        if (!phong) {
-            local = local + (kd / PI_F) * Li * NdotL;
-            const f3 H = normalized3(Ldir + V);
-            const float NdotH = fmaxf(0.0f, dot3(N, H));
-            if (NdotH > 0.0f) local = local + (ks * (alpha + 2.0f) / (8.0f * PI_F)) * Li * rtx_powf(NdotH, alpha);
-        } else {
-            f3 lightContrib = (kd / PI_F) * Li * NdotL;
-            const f3 R = normalized3(2.0f * dot3(N, Ldir) * N - Ldir);
-            const float RdotV = fmaxf(0.0f, dot3(R, V));
-            if (RdotV > 0.0f) lightContrib = lightContrib + (ks * (alpha + 1.0f) / (2.0f * PI_F)) * Li * rtx_powf(RdotV, alpha);
-            local = local + lightContrib;
-        }
-    }
-
-    // indirect light (:419-457)
-    f3 indirect = mk3(0.0f), causticTerm = mk3(0.0f);
-    const bool hasDiffuse = max3c(kd) > 1e-6f;
-    if (!G::kPlain && hasDiffuse && g.pmCaustic.n > 0) causticTerm = (kd / PI_F) * estimate_irradiance(g.pmCaustic, sx.P, sx.N);
-    f3 diffDir = mk3(0.0f), diffW = mk3(0.0f);
-    bool pushDiffuse = false;
-    if (!G::kPlain && g.pmGlobal.n > 0 && !(diffuseDepth <= 1)) {
-        indirect = indirect + (kd / PI_F) * estimate_irradiance(g.pmGlobal, sx.P, sx.N);
-    } else if (hasDiffuse && canBounce) {
-        DirInfo si;
-        if (lg_generate_sample<G::kPlain>(sc, m, sx, diffDir, si)) {
-            diffW = wLocal * (si.mult / si.prob);
-            pushDiffuse = true;
-        }
-    }
-    indirect = indirect + causticTerm;
-    local = local + indirect;
-    S.L = S.L + wLocal * local + w * eval_tc(sc, m.ke, m.ke_tex, sx.uvw);
-
-    // calls are queued in reverse so that they are traced in the reference's order: diffuse, reflection, refraction
+    // reflection / refraction (:459-508), queued first = traced last
     if (spawn) {
+        fl |= LG_F_SPAWN | (isDielectric ? LG_F_DIEL : 0u);
         const float kr = isDielectric ? lg_fresnel_exact(I, N, m.ior) : 1.0f;
+        const f3 reflMul = isDielectric ? mk3(kr) : refl;
+        F.reflMul = reflMul;
         if (isDielectric) {
+            const f3 refrMul = (1.0f - kr) * refrRaw;
+            F.oneMinusRefl = mk3(1.0f) - refl;
+            F.refrMul = refrMul;
             float n1 = 1.0f, n2 = m.ior;
             const float cosi = -dot3(N, I);
             if (!sx.front) {
@@ -480,52 +477,91 @@ __device__ __forceinline__ void lg_shade(const G& g, const DevMaterial& m, const
             }
             const float eta = n1 / n2;
             const float k = 1.0f - eta * eta * (1.0f - cosi * cosi);
-            if (k >= 0.0f) {
+            if (k >= 0.0f && !(refrMul.x == 0.0f && refrMul.y == 0.0f && refrMul.z == 0.0f)) {
                 f3 T = eta * I + (eta * cosi - sqrtf(k)) * N;
                 T = normalized3(T);
                 const f3 dir = lg_glossy_dir(sx, T, alpha, false, V);
-                lg_push(S, sx, dir, w * ((1.0f - kr) * refrRaw), ld3(m.absorption), node * 3u + 3u, bounce + 1, diffuseDepth);
+                lg_push(S, sx, dir, ld3(m.absorption), node * 3u + 3u, bounce + 1, diffuseDepth, 3u);
             }
         }
-        const f3 rdir = lg_glossy_dir(sx, N, alpha, true, V);
-        lg_push(S, sx, rdir, isDielectric ? w * kr : w * refl, mk3(0.0f), node * 3u + 2u, bounce + 1, diffuseDepth);
+        if (!(reflMul.x == 0.0f && reflMul.y == 0.0f && reflMul.z == 0.0f)) {
+            const f3 rdir = lg_glossy_dir(sx, N, alpha, true, V);
+            lg_push(S, sx, rdir, mk3(0.0f), node * 3u + 2u, bounce + 1, diffuseDepth, 2u);
+        }
     }
-    if (pushDiffuse) lg_push(S, sx, diffDir, diffW, mk3(0.0f), node * 3u + 1u, bounce + 1, diffuseDepth);
-    if (DEFER) {
-        // direct light with the shadow queries queued: the factor of Li in `local` rides with each query. Queued last =
-        // traced first, so the stack never holds the shadow queries of two Shade() calls.
-        for (int l = 0; l < sc.n_lights; ++l) {
-            const DevLight& light = sc.lights[l];
-            const f3 Ldir = normalized3(normalized3(ld3(light.pos) - sx.P));
-            const float NdotL = fmaxf(0.0f, dot3(N, Ldir));
-            if (!(NdotL > 0.0f)) continue;
-            f3 per = (kd / PI_F) * NdotL;
-            if (!phong) {
-                const f3 H = normalized3(Ldir + V);
-                const float NdotH = fmaxf(0.0f, dot3(N, H));
-                if (NdotH > 0.0f) per = per + (ks * (alpha + 2.0f) / (8.0f * PI_F)) * rtx_powf(NdotH, alpha);
-            } else {
-                const f3 R = normalized3(2.0f * dot3(N, Ldir) * N - Ldir);
-                const float RdotV = fmaxf(0.0f, dot3(R, V));
-                if (RdotV > 0.0f) per = per + (ks * (alpha + 1.0f) / (2.0f * PI_F)) * rtx_powf(RdotV, alpha);
-            }
-            lg_illuminate_deferred(sx, obj, light, l, wLocal * per, S);
+
+    // indirect light (:419-457)
+    const bool hasDiffuse = max3c(kd) > 1e-6f;
+    if (!G::kPlain && hasDiffuse && g.pmCaustic.n > 0) {
+        F.caustic = (kd / PI_F) * estimate_irradiance(g.pmCaustic, sx.P, sx.N);
+        fl |= LG_F_CAUSTIC;
+    }
+    if (!G::kPlain && g.pmGlobal.n > 0 && !(diffuseDepth <= 1)) {
+        F.indirect = mk3(0.0f) + (kd / PI_F) * estimate_irradiance(g.pmGlobal, sx.P, sx.N);
+        fl |= LG_F_INDIRECT;
+    } else if (hasDiffuse && canBounce) {
+        f3 diffDir;
+        DirInfo si;
+        if (lg_generate_sample<G::kPlain>(sc, m, sx, diffDir, si) && !(si.mult.x == 0.0f && si.mult.y == 0.0f && si.mult.z == 0.0f)) {
+            F.diffMult = si.mult;
+            F.diffProb = si.prob;
+            lg_push(S, sx, diffDir, mk3(0.0f), node * 3u + 1u, bounce + 1, diffuseDepth, 1u);
         }
+    }
+    S.topFlags = fl;
+
+    // direct light (USE_PHOTON_MAP_DIRECT = false), the last light first
+    for (int l = sc.n_lights - 1; l >= 0; --l) {
+        const DevLight& light = sc.lights[l];
+        const f3 Ldir = normalized3(normalized3(ld3(light.pos) - sx.P));   // Illuminate's dir, then Ldir.Normalize() (:408)
+        const float NdotL = fmaxf(0.0f, dot3(N, Ldir));
+        if (!(NdotL > 0.0f)) continue;   // the reference calls Illuminate first and drops its result here (:406-410)
+        f3 Li, sdir;
+        if (!lg_illuminate_deferred(sx, light, l, Li, sdir)) continue;
+        f3 t1 = (kd / PI_F) * Li * NdotL, t2 = mk3(0.0f);
+        bool hasT2 = false;
+        if (!phong) {
+            const f3 H = normalized3(Ldir + V);
+            const float NdotH = fmaxf(0.0f, dot3(N, H));
+            if (NdotH > 0.0f) {
+                t2 = (ks * (alpha + 2.0f) / (8.0f * PI_F)) * Li * rtx_powf(NdotH, alpha);
+                hasT2 = true;
+            }
+        } else {
+            const f3 R = normalized3(2.0f * dot3(N, Ldir) * N - Ldir);
+            const float RdotV = fmaxf(0.0f, dot3(R, V));
+            if (RdotV > 0.0f) t1 = t1 + (ks * (alpha + 1.0f) / (2.0f * PI_F)) * Li * rtx_powf(RdotV, alpha);   // lightContrib, added once
+        }
+        if (t1.x == 0.0f && t1.y == 0.0f && t1.z == 0.0f && t2.x == 0.0f && t2.y == 0.0f && t2.z == 0.0f) continue;
+        lg_push_shadow(sx, obj, sdir, 1.0f, t1, t2, hasT2, S);
     }
 }
 
-// TraceSecondaryRay from the biased ray on (ShadeInfoAdapter.h:114-230) for every queued call; firstDist receives the
-// `dist` result of the first call traced (the one a caller of rtx_trace_secondary asked for)
+// A traced call returns: c is the call, h the closest hit of its ray (isRoot: the camera ray's hit, traced by extend_kernel).
+// Shadow query: the light's terms enter the open frame. Secondary ray: TraceSecondaryRay from the hit on
+// (ShadeInfoAdapter.h:114-230) - a renderable light in front of the geometry, the environment, or the Shade() of the
+// surface hit, whose frame is opened here. Closes whatever frames this completes.
+struct LgRootOut {
+    float primaryDist;
+    f3 normal, albedo;
+    bool hit;        // a surface was hit (normal valid)
+    bool shaded;     // ... and it has a material (albedo valid)
+};
 template <class G>
-__device__ __forceinline__ void lg_run(const G& g, unsigned long long key, LgState& S, float* firstDist = nullptr) {
+__device__ __forceinline__ void lg_complete(const G& g, unsigned long long key, const LgCall& c, const HitT& h, bool isRoot, LgState& S,
+                                            LgRootOut* ro, float* distOut) {
     const auto& sc = g.sc;
-    bool first = true;
-    while (S.sp > 0) {
-        const LgCall c = S.stack[--S.sp];
-        const bool isFirst = first;
-        first = false;
-        const RayT r{c.o.x, c.o.y, c.o.z, c.d.x, c.d.y, c.d.z, RTX_BIG};
-        S.rays++;
+    if (c.kind & LG_SHADOW_CALL) {
+        if (lg_shadow_visible(sc, c, h)) {
+            S.topLocal = S.topLocal + c.a;
+            if (c.kind & 1u) S.topLocal = S.topLocal + c.b;
+        }
+        lg_unwind(S);
+        return;
+    }
+    const uint32_t slot = (c.kind >> 16) & 3u;
+    const RayT r{c.o.x, c.o.y, c.o.z, c.d.x, c.d.y, c.d.z, RTX_BIG};
+    if (!isRoot) {   // nearest renderable light against the closest geometry hit
         float bestLightT = RTX_BIG;
         int visibleLight = -1;
         for (int l = 0; l < sc.n_lights; ++l) {
@@ -535,43 +571,71 @@ __device__ __forceinline__ void lg_run(const G& g, unsigned long long key, LgSta
                 visibleLight = l;
             }
         }
-        uint32_t nc = 0, tc = 0;
-        const HitT h = traverse_closest<false>(sc, r, RTX_HIT_FRONT_AND_BACK, g.st, &nc, &tc);
         const bool hitGeom = h.slot >= 0;
         if (visibleLight >= 0 && (!hitGeom || bestLightT < h.t)) {
             const DevLight& light = sc.lights[visibleLight];
             const f3 rad = clamp01_3(ld3(light.intensity) / (PI_F * light.size * light.size));
-            S.L = S.L + c.w * (rad * lg_absorption_factor(c.absorb, bestLightT));
-            if (isFirst && firstDist) *firstDist = bestLightT;
-            continue;
+            if (distOut) *distOut = bestLightT;
+            lg_deliver(S, slot, rad * lg_absorption_factor(c.a, bestLightT));
+            lg_unwind(S);
+            return;
         }
         if (!hitGeom) {
             const f3 nd = normalized3(c.d);
             const f3 env = sc.env_tex >= 0 ? ld3(sc.env) * tex_eval_env(sc, sc.env_tex, nd) : ld3(sc.env);
-            S.L = S.L + c.w * (env * lg_absorption_factor(c.absorb, RTX_BIG));
-            continue;
+            lg_deliver(S, slot, env * lg_absorption_factor(c.a, RTX_BIG));
+            lg_unwind(S);
+            return;
         }
-        SurfHit sh;
-        resolve_triangle(sc, r, h, sh);
-        const float hitDist = len3(sh.p - c.o);
-        const float dist = sh.front ? hitDist : 0.0f;
-        if (isFirst && firstDist) *firstDist = dist;
-        const int mi = sc.objs[sh.obj].material;
-        if (mi < 0) continue;
-        const DevMaterial& m = sc.mtls[mi];
-        apply_bump(sc, m, sh);
-        SampCtx sx;
-        sx.P = sh.p;
-        sx.V = -normalized3(c.d);
-        sx.N = sh.N;
-        sx.GN = sh.GN;
-        sx.uvw = sh.uvw;
-        sx.front = sh.front;
-        sx.key = key;
-        sx.stream = c.node;
-        const int bounce = (int)(c.bounceDepth & 0xFFu);
-        const int dd = (int)(c.bounceDepth >> 8) + (mtl_is_photon_surface(m) ? 1 : 0);
-        lg_shade<false>(g, m, sx, sh.obj, c.w * lg_absorption_factor(c.absorb, dist), bounce, dd, S);
+    }
+    SurfHit sh;
+    resolve_triangle(sc, r, h, sh);
+    const float hitDist = len3(sh.p - c.o);
+    const float dist = (isRoot || !sh.front) ? 0.0f : hitDist;   // the root carries no absorption
+    if (distOut) *distOut = dist;
+    const int mi = sc.objs[sh.obj].material;
+    if (ro) {
+        ro->primaryDist = hitDist;
+        ro->normal = safe_normalize3(sh.GN);
+        ro->hit = true;
+        ro->shaded = mi >= 0;
+    }
+    if (mi < 0) {
+        lg_deliver(S, slot, mk3(0.0f));
+        lg_unwind(S);
+        return;
+    }
+    const DevMaterial& m = sc.mtls[mi];
+    apply_bump(sc, m, sh);
+    SampCtx sx;
+    sx.P = sh.p;
+    sx.V = -normalized3(c.d);
+    sx.N = sh.N;
+    sx.GN = sh.GN;
+    sx.uvw = sh.uvw;
+    sx.front = sh.front;
+    sx.key = key;
+    sx.stream = c.node;
+    if (ro) ro->albedo = (!G::kPlain && m.type == RTX_MTL_MICROFACET) ? mk3(0.5f) : eval_tc(sc, m.kd, m.kd_tex, sx.uvw);   // GetDiffuseAlbedo :135-138
+    const int bounce = (int)(c.kind & 0xFFu);
+    const int dd = isRoot ? 0 : (int)((c.kind >> 8) & 0xFFu) + (mtl_is_photon_surface(m) ? 1 : 0);
+    lg_shade(g, m, sx, sh.obj, isRoot ? 0u : slot, lg_absorption_factor(c.a, dist), bounce, dd, S);
+    lg_unwind(S);
+}
+
+// every queued call traced to its end, one after the other (legacy_secondary_kernel); firstDist receives the `dist`
+// result of the first call traced (the one a caller of rtx_trace_secondary asked for)
+template <class G>
+__device__ __forceinline__ void lg_run(const G& g, unsigned long long key, LgState& S, float* firstDist = nullptr) {
+    bool first = true;
+    while (S.sp > 0) {
+        const LgCall& c = S.stack[--S.sp];
+        const RayT r{c.o.x, c.o.y, c.o.z, c.d.x, c.d.y, c.d.z, RTX_BIG};
+        if (!(c.kind & LG_SHADOW_CALL)) S.rays++;
+        uint32_t nc = 0, tc = 0;
+        const HitT h = traverse_closest<false>(g.sc, r, RTX_HIT_FRONT_AND_BACK, g.st, &nc, &tc);
+        lg_complete(g, key, c, h, false, S, nullptr, first ? firstDist : nullptr);
+        first = false;
     }
 }
 
@@ -607,15 +671,16 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene scArg, DevC
     // is done takes its next one at once (one recursion tree can be 30 times another's).
     LgState st;
     st.L = mk3(0.0f);
-    st.sp = 0;
+    st.sp = st.fp = 0;
     st.rays = st.shadows = 0;
+    st.topLocal = mk3(0.0f);
+    st.topBase = st.topFlags = 0u;
     TravState ts;
     ts.cur = RTX_TRAV_DONE;
     ts.sp = 0;
     TravStack tstack = g.st;
-    LgCall c;
-    c.o = c.d = c.w = c.absorb = mk3(0.0f);
-    c.node = c.bounceDepth = 0u;
+    // the call being traced stays where it was popped from, st.stack[st.sp] (the slot above the stack's top), until its ray
+    // has finished: only the ray itself (ts) is live across the traversal steps
     HitT rootH{0.0f, 0.0f, 0.0f, -1};
     bool have = false;            // this lane holds a sample
     bool inFlight = false;        // c is being traced (ts)
@@ -629,10 +694,10 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene scArg, DevC
         // ---- idle lanes take their next call, or their next sample ----
         if (!inFlight && !rootPending && !finished) {
             if (st.sp > 0) {
-                c = st.stack[--st.sp];
-                trav_init(ts, sc, RayT{c.o.x, c.o.y, c.o.z, c.d.x, c.d.y, c.d.z, RTX_BIG});
+                const LgCall& cc = st.stack[--st.sp];
+                trav_init(ts, sc, RayT{cc.o.x, cc.o.y, cc.o.z, cc.d.x, cc.d.y, cc.d.z, RTX_BIG});
                 inFlight = true;
-                if (c.bounceDepth != LG_SHADOW_CALL) st.rays++;
+                if (!(cc.kind & LG_SHADOW_CALL)) st.rays++;
             } else {
                 if (have) {
                     pool.L[slot] = make_float4(st.L.x, st.L.y, st.L.z, primaryDist);
@@ -678,12 +743,12 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene scArg, DevC
                     } else {
                         rootPending = true;
                         rootH = h;
-                        c.o = rorg;
-                        c.d = rdir;
-                        c.w = mk3(1.0f);
-                        c.absorb = mk3(0.0f);
-                        c.node = 0u;
-                        c.bounceDepth = 0u;
+                        LgCall& cc = st.stack[0];   // st.sp == 0 here
+                        cc.o = rorg;
+                        cc.d = rdir;
+                        cc.a = cc.b = mk3(0.0f);
+                        cc.node = 0u;
+                        cc.kind = 0u;
                     }
                 }
             }
@@ -714,69 +779,20 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene scArg, DevC
         const HitT h = isRoot ? rootH : ts.best;
         inFlight = false;
         rootPending = false;
-        if (c.bounceDepth == LG_SHADOW_CALL) {
-            if (lg_shadow_visible(sc, c, h)) st.L = st.L + c.w;
-            continue;
+        LgRootOut ro;
+        ro.hit = ro.shaded = false;
+        const LgCall& c = st.stack[st.sp];   // read before lg_shade pushes over it
+        lg_complete(g, key, c, h, isRoot, st, isRoot ? &ro : nullptr, nullptr);
+        if (isRoot && ro.hit) {
+            primaryDist = ro.primaryDist;
+            pool.normal[slot] = make_float4(ro.normal.x, ro.normal.y, ro.normal.z, 1.0f);
+            pool.albedo[slot] = ro.shaded ? make_float4(ro.albedo.x, ro.albedo.y, ro.albedo.z, 1.0f) : make_float4(0.0f, 0.0f, 0.0f, 1.0f);
         }
-        const RayT r{c.o.x, c.o.y, c.o.z, c.d.x, c.d.y, c.d.z, RTX_BIG};
-        if (!isRoot) {   // TraceSecondaryRay :114-230: nearest renderable light against the closest geometry hit
-            float bestLightT = RTX_BIG;
-            int visibleLight = -1;
-            for (int l = 0; l < sc.n_lights; ++l) {
-                const float t = lg_light_intersect(sc.lights[l], c.o, c.d);
-                if (t > 0.0f && t < bestLightT) {
-                    bestLightT = t;
-                    visibleLight = l;
-                }
-            }
-            const bool hitGeom = h.slot >= 0;
-            if (visibleLight >= 0 && (!hitGeom || bestLightT < h.t)) {
-                const DevLight& light = sc.lights[visibleLight];
-                const f3 rad = clamp01_3(ld3(light.intensity) / (PI_F * light.size * light.size));
-                st.L = st.L + c.w * (rad * lg_absorption_factor(c.absorb, bestLightT));
-                continue;
-            }
-            if (!hitGeom) {
-                const f3 nd = normalized3(c.d);
-                const f3 env = sc.env_tex >= 0 ? ld3(sc.env) * tex_eval_env(sc, sc.env_tex, nd) : ld3(sc.env);
-                st.L = st.L + c.w * (env * lg_absorption_factor(c.absorb, RTX_BIG));
-                continue;
-            }
-        }
-        SurfHit sh;
-        resolve_triangle(sc, r, h, sh);
-        const float hitDist = len3(sh.p - c.o);
-        if (isRoot) primaryDist = hitDist;
-        const float dist = (isRoot || !sh.front) ? 0.0f : hitDist;   // the root carries no absorption
-        const int mi = sc.objs[sh.obj].material;
-        if (isRoot) {
-            const f3 fn = safe_normalize3(sh.GN);
-            pool.normal[slot] = make_float4(fn.x, fn.y, fn.z, 1.0f);
-            if (mi < 0) pool.albedo[slot] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-        }
-        if (mi < 0) continue;
-        const DevMaterial& m = sc.mtls[mi];
-        apply_bump(sc, m, sh);
-        SampCtx sx;
-        sx.P = sh.p;
-        sx.V = -normalized3(c.d);
-        sx.N = sh.N;
-        sx.GN = sh.GN;
-        sx.uvw = sh.uvw;
-        sx.front = sh.front;
-        sx.key = key;
-        sx.stream = c.node;
-        if (isRoot) {
-            const f3 alb = (!PLAIN && m.type == RTX_MTL_MICROFACET) ? mk3(0.5f) : eval_tc(sc, m.kd, m.kd_tex, sx.uvw);   // GetDiffuseAlbedo :135-138
-            pool.albedo[slot] = make_float4(alb.x, alb.y, alb.z, 1.0f);
-        }
-        const int bounce = (int)(c.bounceDepth & 0xFFu);
-        const int dd = isRoot ? 0 : (int)(c.bounceDepth >> 8) + (mtl_is_photon_surface(m) ? 1 : 0);
-        lg_shade<true>(g, m, sx, sh.obj, c.w * lg_absorption_factor(c.absorb, dist), bounce, dd, st);
     }
     atomicAdd(&pool.rayCounters[0], shadows);
     atomicAdd(&pool.rayCounters[1], rays);
 }
+
 
 // ShadeInfoAdapter::TraceSecondaryRay (ShadeInfoAdapter.h:94-231) for n directions from one shading point: the entry
 // point behind rtx_trace_secondary. out[i] = {colour, dist}.
@@ -792,8 +808,10 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_secondary_kernel(DevScene s
     for (uint32_t i = gtid; i < n; i += nThreads) {
         LgState st;
         st.L = mk3(0.0f);
-        st.sp = 0;
+        st.sp = st.fp = 0;
         st.rays = st.shadows = 0;
+        st.topLocal = mk3(0.0f);
+        st.topBase = st.topFlags = 0u;
         float dist = RTX_BIG;
         if (at.bounce < LG_MAX_BOUNCES) {   // CanBounce (:97)
             SampCtx sx;
@@ -804,8 +822,8 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_secondary_kernel(DevScene s
             sx.key = rng_key(seed, (uint32_t)at.pixel, (uint32_t)at.sample);
             sx.stream = at.node;
             // recursive == false: the Shade() reached behaves as at the depth limit (:220-223)
-            lg_push(st, sx, mk3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), mk3(1.0f), mk3(0.0f), at.node * 3u + (uint32_t)child,
-                    recursive ? at.bounce + 1 : LG_MAX_BOUNCES, at.diffuse_depth);
+            lg_push(st, sx, mk3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), mk3(0.0f), at.node * 3u + (uint32_t)child,
+                    recursive ? at.bounce + 1 : LG_MAX_BOUNCES, at.diffuse_depth, (uint32_t)child & 3u);
             lg_run(g, sx.key, st, &dist);
         }
         out[i] = make_float4(st.L.x, st.L.y, st.L.z, dist);

@@ -2,9 +2,10 @@
 RayCaster.cpp:579-631 -> Shade() of Shading_Legacy.cpp through ShadeInfoAdapter's shadow / secondary rays) against the
 CPU oracle, through the C ABI. Same sampler, same counter RNG keyed by the node of the recursion tree.
 
-Tolerance: per-sample radiance within 1e-5 * (1 + |ref|) on >= 99.99 % of the samples (the GPU sums the linear
-recursion tree in a different order and uses fp32 libm of its own; the rest flip a discrete decision - a shadow ray
-grazing an edge, the lobe pick - on an ulp); image RMSE <= 2 % of the mean radiance.
+Bar: every per-sample radiance is the oracle's bit for bit. legacy_kernel evaluates the recursion tree without
+recursion but in the recursion's order and association (a frame per open Shade(), csrc/kernels_legacy.hip), hits,
+elementary functions (rtx_math.h) and random numbers are the same arithmetic on both sides. Images: the film adds a
+pixel's samples in another order than the oracle's loop, so those compare by RMSE.
 """
 import numpy as np
 import pytest
@@ -24,11 +25,10 @@ def small(rtx):
     return sd, cam, rtx.Scene(sd), OracleScene(sd)
 
 
-def frac_within(g, o, tol=1e-5):
-    """The kernel adds the terms of a sample's recursion tree in another order than the recursive oracle; everything
-    else - hits, elementary functions (rtx_math.h), random numbers - is the same arithmetic: 1e-5 * (1 + |ref|)."""
-    d = np.abs(g[..., :3] - o[..., :3]).max(-1)
-    return float((d <= tol * (1 + np.abs(o[..., :3]).max(-1))).mean())
+def same_bits(g, o):
+    """Colour channels bit-identical (NaN patterns aside: there are none in these scenes)."""
+    g, o = np.ascontiguousarray(g[..., :3], np.float32), np.ascontiguousarray(o[..., :3], np.float32)
+    return bool(np.array_equal(g.view(np.uint32), o.view(np.uint32)))
 
 
 def test_per_sample_radiance(small):
@@ -38,7 +38,7 @@ def test_per_sample_radiance(small):
     o = osc.render_samples(cam, rp)
     assert np.isfinite(g).all()
     assert np.array_equal(g[..., 3], o[..., 3])                        # primary distance
-    assert frac_within(g, o) >= 0.9999
+    assert same_bits(g, o)
     assert (g[..., :3] > 10.0).any() or (o[..., :3] <= 10.0).all()     # no radiance clamp in this mode
     assert st["rays_primary"] == cam.width * cam.height * 4
     assert st["rays_bounce"] > st["rays_primary"]                      # the recursion fans out
@@ -54,7 +54,7 @@ def test_image_and_adaptive_rounds(small):
     g, o = gs.render(cam, rp), osc.render(cam, rp)
     rmse = np.sqrt(np.mean((g["linear"] - o["linear"]) ** 2))
     assert rmse <= 1e-4 * o["linear"].mean(), rmse
-    assert (g["samples"] == o["samples"]).mean() >= 0.9995          # a pixel whose half-width sits on the threshold
+    assert (g["samples"] == o["samples"]).mean() >= 0.9995          # a pixel whose half-width sits on the threshold (film sums in another order)
     assert np.array_equal(g["z"], o["z"])
 
 
@@ -68,9 +68,9 @@ def test_photon_maps_in_legacy_mode(small, rtx):
     rp = render_params(spp_min=2, use_photons=1, shading_mode=LEGACY)
     g, _ = gs.render_samples(cam, rp, gp)
     o = osc.render_samples(cam, rp, op)
-    # both sides evaluate the same elementary functions, so the two maps hold the same photons and every sample gathers
-    # the same ones; the cone-filtered sum runs in grid order on the GPU and in map order in the oracle
-    assert frac_within(g, o) >= 0.9999
+    # both sides evaluate the same elementary functions, so the two maps hold the same photons in the same storage order
+    # and every sample gathers the same ones in the same order
+    assert same_bits(g, o)
     # Rendering again must give the same bits: the first render of a process sees zeroed scratch memory, later ones do
     # not (a spill store the compiler had placed before the lanes of root hits were re-enabled showed up exactly here,
     # DESIGN.md "Toolchain notes"; raytracer_amd/csrc `make spillcheck` looks for that placement in the assembly)
@@ -109,7 +109,7 @@ def test_materials_and_objects(rtx):
     g, _ = gs.render_samples(cam, rp)
     o = osc.render_samples(cam, rp)
     assert np.isfinite(g).all()
-    assert frac_within(g, o) >= 0.9999
+    assert same_bits(g, o)
     assert o[..., :3].max() > 0.5
 
 
@@ -131,7 +131,7 @@ def test_trace_secondary_entry_point(small):
         big = o[:, 3] > 1e29
         assert np.array_equal(g[:, 3] > 1e29, big)
         assert np.array_equal(g[~big, 3], o[~big, 3])
-        assert frac_within(g, o) >= 0.9999
+        assert same_bits(g, o)
         assert (~big).sum() > 100 and o[:, :3].max() > 0
     single = osc.trace_secondary(at, d, recursive=False, child=2)
     full = osc.trace_secondary(at, d, recursive=True, child=2)
@@ -148,13 +148,13 @@ def test_golden_legacy_fixture(rtx):
     gs = rtx.Scene(synth.build_scene(0.002))
     cam = synth.cerealbar_camera(48, 27)
     s, _ = gs.render_samples(cam, render_params(spp_min=4, shading_mode=LEGACY))
-    assert frac_within(s, g["samples"]) >= 0.9999
+    assert same_bits(s, g["samples"])
     at = _ffi.ShadePoint()
     at.P[:] = (0.9, 0.35, 0.2)
     at.N[:] = (0.0, 1.0, 0.0)
     at.obj, at.bounce, at.diffuse_depth, at.pixel, at.sample, at.node = -1, 1, 0, 77, 1, 1
     sec = gs.trace_secondary(at, g["dirs"], recursive=True, child=1)
-    assert frac_within(sec, g["secondary"]) >= 0.9999
+    assert same_bits(sec, g["secondary"])
 
 
 def test_more_samples_than_resident_lanes(rtx):
@@ -176,5 +176,5 @@ def test_more_samples_than_resident_lanes(rtx):
     xys[:64] = [[x, y, s] for x, y, s in zip(range(W - 64, W), [H - 1] * 64, [spp - 1] * 64)]   # the last samples handed out
     o = osc.trace_samples(cam, rp, xys)
     gsub = g[xys[:, 1], xys[:, 0], xys[:, 2]]
-    assert frac_within(gsub, o) >= 0.9999
+    assert same_bits(gsub, o)
     assert np.array_equal(gsub[:, 3], o[:, 3])

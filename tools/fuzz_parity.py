@@ -366,7 +366,7 @@ def main():
             flag = "" if (ag >= need and dz.mean() >= 0.999 and (fin or not ofin)) else "   <-- CHECK"
             ex = float(((g.view(np.uint32) == o.view(np.uint32)) | (np.isnan(g) & np.isnan(o))).all(-1).mean())
             if EXACT:
-                ok = ex == 1.0 if mode == _ffi.SHADING_PATH else (agree(g, o, 1e-5) >= 0.9999 and same_bits(g[..., 3], o[..., 3]))
+                ok = ex == 1.0   # both shading modes: every sample the oracle's bits
                 flag = "" if ok else "   <-- CHECK"
             if flag:
                 bad.append((seed, mode))
