@@ -80,7 +80,9 @@ void launch_film(const PathPool& pool, const rtx_film& film, const int* pixels, 
 // legacy shading mode (kernels_legacy.hip): TraceLegacy for the n camera samples whose primary hits are in pool.hits
 void launch_legacy(const DevScene& sc, const LaunchCfg& cfg, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pmGlobal,
                    const DevPhotonMap& pmCaustic, const SegQ& qIn, const uint32_t* queueIn, uint32_t n, unsigned long long seed,
-                   int sBase, int S, const int* pixels, int blinnOnly);
+                   int sBase, int S, const int* pixels, int blinnOnly, void* state);
+// bytes of `state`: the calls and frames of every lane of the persistent grid (allocated once per path pool)
+size_t legacy_state_bytes(const LaunchCfg& cfg);
 void launch_legacy_secondary(const DevScene& sc, const LaunchCfg& cfg, const DevPhotonMap& pmGlobal, const DevPhotonMap& pmCaustic,
                              const rtx_shade_point& at, const float* dirs, uint32_t n, int recursive, int child, unsigned long long seed,
                              float4* out);

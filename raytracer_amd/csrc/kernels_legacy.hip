@@ -34,13 +34,18 @@
 #define LG_LEAF_WEIGHT 1u
 #endif
 
-struct LgCall {                 // one pending TraceSecondaryRay call or TraceShadowRay query
-    f3 o, d;                    // biased origin, unit direction (:99-112 / :57-70)
-    f3 a, b;                    // secondary ray: a = Beer-Lambert coefficients over the call's `dist` (refraction rays), else 0
-                                // shadow query: the light's terms of `local`, added in this order if nothing blocks
-    float selfDist, limit;      // shadow query: hits of the receiver closer than selfDist are ignored; blocked before `limit`
-                                // (< 0: unbounded segment; -2: TraceShadowRay returns 1 whatever is hit)
+// Calls and frames live in global memory, one contiguous block per lane of the persistent grid (launch_legacy's
+// `state`): a call is one 64-byte line, a frame's everyday fields are one line. In compiler scratch a private array is
+// interleaved dword by dword over the lanes of a wave, and once the lanes' stack heights differ every dword of a call
+// becomes a 64-byte request of its own (first frame version: 2.6x the L2 writes of the flattened kernel).
+struct alignas(16) LgCall {     // one pending TraceSecondaryRay call or TraceShadowRay query
+    f3 o;                       // biased origin (:99-112 / :57-70)
+    float selfDist;             // shadow query: hits of the receiver closer than this are ignored
+    f3 d;                       // unit direction
+    float limit;                // shadow query: blocked before `limit` (< 0: unbounded segment; -2: TraceShadowRay returns 1 whatever is hit)
+    f3 a;                       // secondary ray: Beer-Lambert coefficients over the call's `dist` (refraction rays), else 0
     uint32_t node;              // secondary ray: RNG node of the Shade() the call leads to; shadow query: the receiver's object
+    f3 b;                       // shadow query: a, b = the light's terms of `local`, added in this order if nothing blocks
     uint32_t kind;              // secondary ray: bounce of that Shade() | diffuse depth of the caller << 8 | slot << 16
                                 // (1 diffuse, 2 reflection, 3 refraction: where the colour goes in the caller's frame)
 };
@@ -56,21 +61,35 @@ struct LgCall {                 // one pending TraceSecondaryRay call or TraceSh
 #define LG_F_REFLC 512u
 #define LG_F_REFRC 1024u
 // One open Shade(). The frame is written and read field by field, and only the fields a Shade() needs (a diffuse
-// surface: diffMult, diffProb, indirect): the frames and the call stack live in scratch memory, 2.4 KB per lane that no
-// cache holds for a whole grid, and the kernel's time follows that traffic.
-struct LgFrame {
+// surface: diffMult, diffProb, indirect): 2.4 KB of calls and frames per lane is more than any cache holds for a whole
+// grid, and the kernel's time follows that traffic.
+struct alignas(16) LgFrame {
     f3 local;                   // `local` so far (microfacet: `result`), base, flags: valid while a deeper frame is open
     uint32_t base;              //   (the innermost frame's copies are LgState::topLocal / topBase / topFlags)
-    uint32_t flags;
     f3 diffMult;                // diffuse bounce: indirect = colour * diffMult / diffProb (microfacet: colour * diffMult)
     float diffProb;
     f3 indirect;                // global-map term, or the diffuse bounce once its colour is in (:419-457)
+    uint32_t flags;
     f3 caustic;
-    f3 oneMinusRefl, reflMul, refrMul;   // :499-507
-    f3 reflC, refrC;            // colours of the reflection / refraction call
+    uint32_t pad0;              // ---- 64 bytes: all a diffuse surface touches ----
+    f3 oneMinusRefl;            // :499-507
+    uint32_t pad1;
+    f3 reflMul;
+    uint32_t pad2;
+    f3 refrMul;
+    uint32_t pad3;
+    f3 reflC;                   // colours of the reflection / refraction call
+    uint32_t pad4;
+    f3 refrC;
+    uint32_t pad5;
     f3 emission;
+    uint32_t pad6;
     f3 retFactor;               // Beer-Lambert factor on the result (a refraction call's hit, :359)
+    uint32_t pad7;
+    uint32_t pad8[4];
 };
+static_assert(sizeof(LgCall) == 64 && sizeof(LgFrame) == 192, "one call = one 64-byte line, one frame = three");
+#define LG_LANE_BYTES (LG_STACK * sizeof(LgCall) + LG_FRAMES * sizeof(LgFrame))
 
 struct LgState {
     f3 L;                       // the sample's radiance once the root frame has closed
@@ -80,8 +99,8 @@ struct LgState {
     f3 topLocal;
     uint32_t topBase;           // height of the call stack when the frame was opened
     uint32_t topFlags;
-    LgCall stack[LG_STACK];
-    LgFrame frames[LG_FRAMES];
+    LgCall* stack;              // LG_STACK entries
+    LgFrame* frames;            // LG_FRAMES entries
 };
 
 // PLAIN: Blinn materials only and no photon maps in this call (launch_legacy decides): the Phong and microfacet forms of
@@ -653,7 +672,7 @@ __attribute__((amdgpu_waves_per_eu(LEGACY_WAVES_PER_EU)))
 __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene scArg, DevCamera cam, PathPool pool, DevPhotonMap pmGlobal,
                                                             DevPhotonMap pmCaustic, SegQ qIn, const uint32_t* __restrict__ queueIn,
                                                             uint32_t n, unsigned long long seed, int sBase, int S,
-                                                            const int* __restrict__ pixels, uint2* spill) {
+                                                            const int* __restrict__ pixels, uint2* spill, char* state) {
     __shared__ uint32_t qtab[SEGQ_TABLE_WORDS];
     __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
     segq_load_table(qIn, qtab);
@@ -675,6 +694,8 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene scArg, DevC
     st.rays = st.shadows = 0;
     st.topLocal = mk3(0.0f);
     st.topBase = st.topFlags = 0u;
+    st.stack = reinterpret_cast<LgCall*>(state + (size_t)gtid * LG_LANE_BYTES);
+    st.frames = reinterpret_cast<LgFrame*>(st.stack + LG_STACK);
     TravState ts;
     ts.cur = RTX_TRAV_DONE;
     ts.sp = 0;
@@ -806,7 +827,11 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_secondary_kernel(DevScene s
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, nThreads = gridDim.x * blockDim.x;
     const LgSceneT<DevSceneT<XF>> g{sc, pmGlobal, pmCaustic, TravStack{&lds_stack[threadIdx.x], spill + gtid, nThreads}};
     for (uint32_t i = gtid; i < n; i += nThreads) {
+        LgCall stackMem[LG_STACK];     // a handful of rays per call of the entry point: compiler scratch will do
+        LgFrame frameMem[LG_FRAMES];
         LgState st;
+        st.stack = stackMem;
+        st.frames = frameMem;
         st.L = mk3(0.0f);
         st.sp = st.fp = 0;
         st.rays = st.shadows = 0;
@@ -830,6 +855,8 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_secondary_kernel(DevScene s
     }
 }
 
+size_t legacy_state_bytes(const LaunchCfg& cfg) { return (size_t)cfg.gridBlocks * TRAV_BLOCK * LG_LANE_BYTES; }
+
 void launch_legacy_secondary(const DevScene& sc, const LaunchCfg& cfg, const DevPhotonMap& pmGlobal, const DevPhotonMap& pmCaustic,
                              const rtx_shade_point& at, const float* dirs, uint32_t n, int recursive, int child, unsigned long long seed,
                              float4* out) {
@@ -846,14 +873,14 @@ void launch_legacy_secondary(const DevScene& sc, const LaunchCfg& cfg, const Dev
 
 void launch_legacy(const DevScene& sc, const LaunchCfg& cfg, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pmGlobal,
                    const DevPhotonMap& pmCaustic, const SegQ& qIn, const uint32_t* queueIn, uint32_t n, unsigned long long seed,
-                   int sBase, int S, const int* pixels, int blinnOnly) {
+                   int sBase, int S, const int* pixels, int blinnOnly, void* state) {
     if (!n) return;
     const uint32_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
     const uint32_t grid = need < (uint32_t)cfg.gridBlocks ? need : (uint32_t)cfg.gridBlocks;
     const bool plain = blinnOnly && pmGlobal.n <= 0 && pmCaustic.n <= 0;
 #define RTX_LAUNCH_LEGACY(X, P)                                                                                                          \
     hipLaunchKernelGGL((legacy_kernel<X, P>), dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, cam, pool, pmGlobal, pmCaustic, qIn, queueIn, \
-                       n, seed, sBase, S, pixels, cfg.spill)
+                       n, seed, sBase, S, pixels, cfg.spill, (char*)state)
     if (sc.has_xf) {
         if (plain) RTX_LAUNCH_LEGACY(true, true);
         else RTX_LAUNCH_LEGACY(true, false);

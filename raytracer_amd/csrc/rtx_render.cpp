@@ -27,6 +27,7 @@ struct PathPoolHost {
     void* sortTemp = nullptr;     // in allocs
     hipEvent_t evTotal0 = nullptr, evTotal1 = nullptr;   // whole-call timing; owned here so that no error path leaks them
     uint2* sideSpill = nullptr;   // its own traversal spill slab (both kernels are in flight at once)
+    char* legacyState = nullptr;  // in allocs: legacy_kernel's calls and frames (legacy shading mode only)
     size_t sortTempBytes = 0;
     void release() {
         if (sideStream) {
@@ -46,6 +47,7 @@ struct PathPoolHost {
         if (evTotal1) (void)hipEventDestroy(evTotal1);
         evTotal0 = evTotal1 = nullptr;
         sideSpill = nullptr;   // in allocs
+        legacyState = nullptr;
         for (void* p : allocs) (void)hipFree(p);
         allocs.clear();
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
@@ -389,6 +391,12 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
             launch_segq_scan(sqIn, gridGen, 256, 1, pool.totals, 2, st);
             uint32_t n = (uint32_t)(curValid * (size_t)Sp);   // = totals[2]: every valid pixel generates Sp paths
             out.paths += n;
+            if (legacy && n > 0 && !ph->legacyState) {
+                if ((rc = pool_alloc(ph, &ph->legacyState, legacy_state_bytes(s->cfg))) != RTX_OK) {
+                    rtx_scene_release_pool(s);
+                    return rc;
+                }
+            }
             if (legacy && n > 0) {
                 // primary hits by the extend kernel, then the whole recursion of every sample in one kernel
                 out.rays_primary += n;
@@ -398,7 +406,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 out.extend_launches++;
                 tm.begin(2, st);
                 launch_legacy(s->dev, s->cfg, dc, pool, pmGlobal, pm, sqIn, qin, n, rp->seed, sBase, Sp, curPixels,
-                              (!s->hasMicrofacet && !s->hasPhong) ? 1 : 0);
+                              (!s->hasMicrofacet && !s->hasPhong) ? 1 : 0, ph->legacyState);
                 tm.end(st);
                 RTX_HIP(hipStreamSynchronize(st));   // one pass at a time, so that rtx_cancel is seen between passes
                 n = 0;
