@@ -679,7 +679,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene scArg, DevC
     __syncthreads();
     const DevSceneT<XF> sc(scArg);
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, nThreads = gridDim.x * blockDim.x;
-    const LgSceneT<DevSceneT<XF>, PLAIN> g{sc, pmGlobal, pmCaustic, TravStack{&lds_stack[threadIdx.x], spill + gtid, nThreads}};
+    const LgSceneT<DevSceneT<XF>, PLAIN> g{sc, pmGlobal, pmCaustic, make_trav_stack<true>(&lds_stack[threadIdx.x], spill, gtid, nThreads)};
     unsigned long long rays = 0, shadows = 0;
     // Every lane is a small state machine: it holds one camera sample and its stack of pending calls (secondary rays and
     // the shadow queries of the Shade() just evaluated), and at most one ray in flight. The wave runs ONE kind of step per
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_secondary_kernel(DevScene s
     __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
     const DevSceneT<XF> sc(scArg);
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, nThreads = gridDim.x * blockDim.x;
-    const LgSceneT<DevSceneT<XF>> g{sc, pmGlobal, pmCaustic, TravStack{&lds_stack[threadIdx.x], spill + gtid, nThreads}};
+    const LgSceneT<DevSceneT<XF>> g{sc, pmGlobal, pmCaustic, make_trav_stack(&lds_stack[threadIdx.x], spill, gtid, nThreads)};
     for (uint32_t i = gtid; i < n; i += nThreads) {
         LgCall stackMem[LG_STACK];     // a handful of rays per call of the entry point: compiler scratch will do
         LgFrame frameMem[LG_FRAMES];

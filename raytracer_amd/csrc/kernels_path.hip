@@ -193,7 +193,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
     __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
     const DevSceneT<XF> sc(scArg);
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
-    TravStack st{&lds_stack[threadIdx.x], spill + gtid, gridDim.x * blockDim.x};
+    TravStack st = make_trav_stack(&lds_stack[threadIdx.x], spill, gtid, gridDim.x * blockDim.x);
     uint32_t hops = 0;
     TravState s;
     s.cur = RTX_TRAV_DONE;

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void photon_emit_kernel(DevScene scArg,
     const DevSceneT<XF> sc(scArg);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
-    TravStack st{&lds_stack[threadIdx.x], spill + gtid, gridDim.x * blockDim.x};
+    TravStack st = make_trav_stack(&lds_stack[threadIdx.x], spill, gtid, gridDim.x * blockDim.x);
     // light selection table (PhotonMapBuilder.cpp:82-95)
     float totalIntensity = 0.0f;
     for (int j = 0; j < sc.n_lights; ++j) totalIntensity += sc.lights[j].intensity[0] + sc.lights[j].intensity[1] + sc.lights[j].intensity[2];

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void tail_kernel(DevScene scArg, DevCam
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, q = lane & 3u;
     const int quadBase = (int)(lane & ~3u);
-    TravStack st{&lds_stack[threadIdx.x], spill + gtid, gridDim.x * blockDim.x};
+    TravStack st = make_trav_stack(&lds_stack[threadIdx.x], spill, gtid, gridDim.x * blockDim.x);
     const int nL = sc.n_lights;
     const uint32_t cap = pool.capacity, mult = (uint32_t)max(1, nL);
     uint32_t hops = 0, rays = 0;

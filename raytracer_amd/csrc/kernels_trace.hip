@@ -77,7 +77,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(EXTE
     __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
     const DevSceneT<XF> sc(scArg);
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
-    TravStack st{&lds_stack[threadIdx.x], spill + gtid, gridDim.x * blockDim.x};
+    TravStack st = make_trav_stack<true>(&lds_stack[threadIdx.x], spill, gtid, gridDim.x * blockDim.x);
     uint32_t nodeCount = 0, triCount = 0, rayCount = 0;
     TravState s;
     s.cur = RTX_TRAV_DONE;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void visibility_kernel(DevScene scArg, 
     const DevSceneT<XF> sc(scArg);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
-    TravStack st{&lds_stack[threadIdx.x], spill + gtid, gridDim.x * blockDim.x};
+    TravStack st = make_trav_stack(&lds_stack[threadIdx.x], spill, gtid, gridDim.x * blockDim.x);
     uint32_t hops = 0, nc = 0, tc = 0;
     for (;;) {
         uint32_t base = 0;

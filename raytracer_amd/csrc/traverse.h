@@ -25,7 +25,7 @@ struct HitT {
 };
 
 // Per-lane traversal stack. LDS part is laid out [entry][thread] so that a wave's ds_read_b64/ds_write_b64 are
-// conflict-free; the spill part is [entry][global thread] so that a wave's accesses coalesce.
+// conflict-free; the spill part is [entry][global thread] or [global thread][entry] (make_trav_stack).
 struct TravStack {
     uint2* lds;          // &stack[0][threadIdx.x]
     uint2* spill;        // &slab[0 * stride + gtid]
@@ -43,6 +43,16 @@ struct TravStack {
         return spill[(size_t)(sp - STACK_LDS) * stride];
     }
 };
+
+// the stack of lane gtid of a grid of nThreads lanes; ldsLane = &stack[0][threadIdx.x]. LANE_MAJOR: the spilled part is
+// [global thread][entry] - a lane's entries share 64-byte lines - instead of [entry][global thread]. Measured per kernel
+// (C3): extend 331.4 -> 327.6 ms and the legacy kernel 481 -> 467 ms lane-major, shadow 161.7 -> 170.9 ms (its short
+// traversals seldom go deeper than one spilled entry, which the interleaved rows serve to a whole wave at once).
+template <bool LANE_MAJOR = false>
+__device__ __forceinline__ TravStack make_trav_stack(uint2* ldsLane, uint2* slab, uint32_t gtid, uint32_t nThreads) {
+    if (LANE_MAJOR) return TravStack{ldsLane, slab + (size_t)gtid * STACK_GLOBAL, 1u};
+    return TravStack{ldsLane, slab + gtid, nThreads};
+}
 
 __device__ __forceinline__ float scale_from_exp(uint32_t e) { return __uint_as_float(e << 23); }
 
