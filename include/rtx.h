@@ -454,6 +454,9 @@ int rtx_get_counters(rtx_scene* scene, uint64_t out[3]);
  * conservative); out[0]=triangles, [1]=nodes, [2]=depth.
  * rtx_debug_pixel_list: the padded pixel list (64-pixel wave blocks, -1 = padding) of the buckets that
  * RayCaster.cpp:1152-1158 would build and that belong to `rank` of `world`; returns its length.
+ * rtx_debug_lpt_assign: the deal rtx_group_render makes between adaptive rounds (greedy longest-processing-time: buckets by
+ * decreasing weight then index, each to the least loaded member, ties to the lowest): owner[b] in [0, members) for buckets
+ * with weight > 0, -1 otherwise. The same rule as raytracer_amd/distributed.py::lpt_assign.
  * rtx_debug_queue_layout: geometry of the segmented ray queues (csrc/segqueue.h) for a producer grid of
  * `producer_blocks` blocks of `block_threads` threads appending at most `mult` entries per thread: start[s] = first
  * item index of segment s (64 segments), segment_of_block[b] for every block (array of producer_blocks). */
@@ -466,6 +469,7 @@ int rtx_debug_math(int fn, const float* x, const float* y, size_t n, float* out,
 int rtx_debug_queue_layout(uint32_t producer_blocks, uint32_t block_threads, uint32_t mult, uint32_t start[64],
                            uint32_t* segment_of_block);
 int64_t rtx_debug_pixel_list(int width, int height, int tile, int rank, int world, int* out, size_t capacity);
+int rtx_debug_lpt_assign(const int* weight, size_t n_buckets, int members, int* owner);
 
 #ifdef __cplusplus
 }

@@ -360,6 +360,14 @@ int rtx_group_create(const rtx_scene_desc* desc, const int* device_ids, int n, r
     return RTX_OK;
 }
 
+int rtx_debug_lpt_assign(const int* weight, size_t n_buckets, int members, int* owner) {
+    if (!weight || !owner || members < 1 || members > RTX_GROUP_MAX) return rtx_fail(RTX_ERR_INVALID, "bad argument");
+    std::vector<int> w(weight, weight + n_buckets), o;
+    lpt_assign(w, members, o);
+    std::copy(o.begin(), o.end(), owner);
+    return RTX_OK;
+}
+
 int rtx_group_size(const rtx_group* g) { return g ? (int)g->m.size() : 0; }
 rtx_scene* rtx_group_scene(rtx_group* g, int member) { return (g && member >= 0 && member < (int)g->m.size()) ? g->m[member].scene : nullptr; }
 rtx_photons* rtx_group_photons(rtx_group* g, int member) { return (g && member >= 0 && member < (int)g->m.size()) ? g->m[member].photons : nullptr; }

@@ -122,6 +122,12 @@ def test_lpt_assignment_is_balanced_and_deterministic():
         load = np.bincount(owner[owner >= 0], weights=w[owner >= 0], minlength=world)
         assert load.max() - load.min() <= w.max()      # greedy LPT bound
         assert np.array_equal(owner, lpt_assign(w.copy(), world))
+        # the C++ group path (rtx_group_render between adaptive rounds) deals by the same rule
+        from raytracer_amd import _ffi
+        w32 = np.ascontiguousarray(w, np.int32)
+        own_c = np.full(w32.shape[0], -7, np.int32)
+        assert _ffi.load_library().rtx_debug_lpt_assign(w32.ctypes.data, w32.shape[0], world, own_c.ctypes.data) == 0
+        assert np.array_equal(own_c, owner)
     # a clustered load that the static b % world split handles badly
     w2 = np.zeros(8160, np.int64)
     w2[0:400:8] = 256
