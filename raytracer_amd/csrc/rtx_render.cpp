@@ -28,6 +28,12 @@ struct PathPoolHost {
     hipEvent_t evTotal0 = nullptr, evTotal1 = nullptr;   // whole-call timing; owned here so that no error path leaks them
     uint2* sideSpill = nullptr;   // its own traversal spill slab (both kernels are in flight at once)
     char* legacyState = nullptr;  // in allocs: legacy_kernel's calls and frames (legacy shading mode only)
+    // the pixel list of this rank's buckets, kept on the device between calls (building and uploading it costs the host
+    // 16 ms per 1080p frame, during which the GPU waits): valid while baseKey = {W, H, tile, rank, world} matches
+    int* pixelsBase = nullptr;    // in allocs; never written by the adaptive rounds
+    int baseKey[5] = {0, 0, 0, 0, 0};
+    uint32_t baseN = 0;
+    size_t baseValid = 0;
     size_t sortTempBytes = 0;
     void release() {
         if (sideStream) {
@@ -48,6 +54,8 @@ struct PathPoolHost {
         evTotal0 = evTotal1 = nullptr;
         sideSpill = nullptr;   // in allocs
         legacyState = nullptr;
+        pixelsBase = nullptr;
+        baseKey[0] = 0;
         for (void* p : allocs) (void)hipFree(p);
         allocs.clear();
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
@@ -120,6 +128,7 @@ static int ensure_pool(rtx_scene* s, uint32_t slots, size_t framePixels, size_t 
     PA(counters, 64);
     PA(pixels, ph->framePixels + 64);
     PA(pixelsNext, ph->framePixels + 64);
+    if ((rc = pool_alloc(ph, &ph->pixelsBase, ph->framePixels + 64)) != RTX_OK) return rc;
     PA(statSum, ph->framePixels);
     PA(statSum2, ph->framePixels);
     PA(rayCounters, 8);
@@ -262,9 +271,15 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
             if (p < 0 || p >= W * H) return rtx_fail(RTX_ERR_INVALID, "pixel index outside the frame");
         nValid = list.size();
         list.resize((list.size() + 63) & ~(size_t)63, -1);   // whole waves
-    } else
+    }
+    const int listKey[5] = {W, H, bs, rp->rank, world};
+    auto list_cached = [&](const PathPoolHost* h) { return h && h->pixelsBase && std::memcmp(h->baseKey, listKey, sizeof(listKey)) == 0; };
+    bool cached = !spec && list_cached(reinterpret_cast<PathPoolHost*>(s->pool));
+    if (cached) {
+        nValid = reinterpret_cast<PathPoolHost*>(s->pool)->baseValid;
+    } else if (!spec)
         build_pixel_list(W, H, bs, rp->rank, world, list, nValid);
-    uint32_t nPix = (uint32_t)list.size();
+    uint32_t nPix = cached ? reinterpret_cast<PathPoolHost*>(s->pool)->baseN : (uint32_t)list.size();
 
     DevPhotonMap pm;
     std::memset(&pm, 0, sizeof(pm));
@@ -316,7 +331,15 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     const hipEvent_t evTotal0 = ph->evTotal0, evTotal1 = ph->evTotal1;
     RTX_HIP(hipEventRecord(evTotal0, st));
 
-    if (nPix) RTX_HIP(hipMemcpyAsync(pool.pixels, list.data(), (size_t)nPix * sizeof(int), hipMemcpyHostToDevice, st));
+    if (!spec && !list_cached(ph)) {   // first call with this frame / sharding, or the pool was rebuilt
+        if (list.empty()) build_pixel_list(W, H, bs, rp->rank, world, list, nValid);
+        if (nPix) RTX_HIP(hipMemcpyAsync(ph->pixelsBase, list.data(), (size_t)nPix * sizeof(int), hipMemcpyHostToDevice, st));
+        RTX_HIP(hipStreamSynchronize(st));   // `list` is pageable host memory that goes out of scope with this call
+        std::memcpy(ph->baseKey, listKey, sizeof(listKey));
+        ph->baseN = nPix;
+        ph->baseValid = nValid;
+    } else if (spec && nPix)
+        RTX_HIP(hipMemcpyAsync(pool.pixels, list.data(), (size_t)nPix * sizeof(int), hipMemcpyHostToDevice, st));
     if (!spec) launch_stats_clear(pool, (uint32_t)((size_t)W * H), st);
     RTX_HIP(hipMemsetAsync(pool.rayCounters, 0, 8 * sizeof(unsigned long long), st));
     if (s->cfg.counting) RTX_HIP(hipMemsetAsync(s->cfg.counters, 0, 3 * sizeof(unsigned long long), st));
@@ -373,8 +396,9 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     unsigned long long handedOver = 0;   // paths counted by the device sums but not traced by an extend launch (tail kernel, bounce limit)
     s->cancel.store(0);
     PassTimers tm{ph};
-    int* curPixels = pool.pixels;
-    int* nextPixels = pool.pixelsNext;
+    int* curPixels = spec ? pool.pixels : ph->pixelsBase;
+    int* nextPixels = spec ? pool.pixelsNext : pool.pixels;
+    int* sparePixels = pool.pixelsNext;   // takes the place of pixelsBase in the rotation: the base list is never overwritten
     size_t curValid = nValid;
     int roundBase = spec ? spec->sampleBase : 0;
     for (int round = 0; nPix > 0 && curValid > 0; ++round) {
@@ -538,7 +562,11 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
         RTX_HIP(hipStreamSynchronize(st));
         curValid = cnt;
         nPix = (cnt + 63u) & ~63u;
-        std::swap(curPixels, nextPixels);
+        {
+            int* const done = curPixels;
+            curPixels = nextPixels;
+            nextPixels = (done == ph->pixelsBase) ? sparePixels : done;
+        }
     }
     RTX_HIP(hipEventRecord(evTotal1, st));
     RTX_HIP(hipStreamSynchronize(st));
