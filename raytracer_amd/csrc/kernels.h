@@ -74,6 +74,8 @@ void launch_tail(const DevScene& sc, const LaunchCfg& cfg, const DevCamera& cam,
                  const SegQ& qIn, const uint32_t* queueIn, uint32_t n, int bounce0, int maxBounces, unsigned long long seed, int sBase,
                  int S, const int* pixels, int hasMicrofacet, int usePhotons);
 void launch_shadow(const DevScene& sc, const LaunchCfg& cfg, const PathPool& pool, const SegQ& q, uint32_t n, int useTransmittance);
+// the chains a lean shadow launch set aside (PathPool::cullShadows), through the general kernel; qList: control words of its own
+void launch_shadow_culled(const DevScene& scGeneral, const LaunchCfg& cfg, const PathPool& pool, const SegQ& qList, int useTransmittance);
 void launch_film(const PathPool& pool, const rtx_film& film, const int* pixels, uint32_t nPix, int S, int W, int H, int filterType,
                  float filterRadius, int resetZ, float4* samplesOut, int sBase, int sppTotal, float radianceClamp, int nLights,
                  int usePhotons, hipStream_t stream);

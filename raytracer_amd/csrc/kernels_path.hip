@@ -156,8 +156,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
         slot = queueIn[segq_item_index(qtab, i)];
         const float4 ra = pool.rays[2 * (size_t)slot], rb = pool.rays[2 * (size_t)slot + 1];
         const float4 hv = pool.hits[slot];
-        alive = shade_body<MICRO, false, PHOT, PHONG>(sc, cam, pool, pm, slot, RayT{ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, ra.w},
-                                         HitT{hv.x, hv.y, hv.z, __float_as_int(hv.w)}, bounce, maxBounces, seed, sBase, S, pixels, qShadow);
+        const RayT ray{ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, ra.w};
+        const int hitSlot = __float_as_int(hv.w);
+        // a hit that the reference's box tests would have culled (lean extend kernel: not checked there): the vertex is left
+        // alone and the path goes to the general tail kernel, which traces its ray again (rtx_render.cpp)
+        bool culled = false;
+        if (pool.cullPaths && hitSlot >= 0 && !ref_reaches_triangle(sc, ray, hitSlot, hv.x)) {
+            const uint32_t k = atomicAdd(&pool.totals[4], 1u);
+            if (k < RTX_CULL_CAP) {
+                pool.cullPaths[k] = slot;
+                culled = true;
+            }
+        }
+        if (!culled)
+            alive = shade_body<MICRO, false, PHOT, PHONG>(sc, cam, pool, pm, slot, ray, HitT{hv.x, hv.y, hv.z, hitSlot}, bounce, maxBounces, seed,
+                                                          sBase, S, pixels, qShadow);
     }
     // ---- surviving paths -> next queue ----
     const uint32_t q = segq_append(qOut, alive, 1u);
@@ -184,12 +197,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
 #define SHADOW_REFILL_MIN 16
 #endif
 // useTransmittance: bit 0 = Visible() with transmittance (else VisibleSimple), bit 1 = no early exit (parity checks)
-template <bool XF>
+// CULL (lean kernel only): hops that end on a hit are checked against the reference's box tests (PathPool::cullShadows)
+template <bool XF, bool CULL = false>
 #ifdef SHADOW_WAVES_PER_EU
 __attribute__((amdgpu_waves_per_eu(SHADOW_WAVES_PER_EU)))
 #endif
 __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, PathPool pool, SegQ q, int useTransmittance, uint2* spill,
-                                                            uint32_t chunk) {
+                                                            uint32_t chunk, const uint32_t* __restrict__ items) {
     __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
     const DevSceneT<XF> sc(scArg);
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -201,7 +215,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
     bool active = false, exhausted = false;
     SegWalk walk;
     segq_walk_init(q, walk, gtid >> 6, chunk);
-    uint32_t code = 0;
+    uint32_t code = 0, entry = 0;
     f3 o = mk3(0.0f), d = mk3(0.0f);
     float maxDist = 0.0f, visibility = 1.0f;
     int hop = 0;
@@ -219,7 +233,20 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
         const unsigned long long finMask = __ballot(fin);
         const unsigned long long freeMask = finMask | __ballot(!active);
         if (finMask != 0ull && ((uint32_t)__popcll(freeMask) >= SHADOW_REFILL_MIN || freeMask == ~0ull)) {
-            if (fin && mode != 3 && !trav_verify(s, sc)) {
+            // lean kernel: a hop that ends on a hit the reference's box tests would have culled (not checked on the way: see
+            // ref_box_hit) is not resolved here - the whole chain is traced again by the general kernel (launch_shadow_culled)
+            bool culledHop = false;
+            if (!XF && CULL && fin && mode != 3 && pool.cullShadows && s.best.slot >= 0 && !ref_reaches_triangle(scArg, s.r, s.best.slot, s.best.t)) {
+                const uint32_t k = atomicAdd(&pool.totals[5], 1u);
+                if (k < RTX_CULL_CAP) {
+                    pool.cullShadows[k] = entry;
+                    culledHop = true;
+                }
+            }
+            if (culledHop) {
+                hops -= (uint32_t)hop + 1u;   // counted again there
+                active = false;
+            } else if (fin && mode != 3 && !trav_verify(s, sc)) {
                 mode = 0;   // general kernels: the hop's hit is culled by its object's box in the reference, traced again without that object
             } else if (fin) {
                 bool next = true;
@@ -248,7 +275,8 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
             if (!active) {
                 const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 if (prefix < got) {
-                    const size_t e = first + prefix;
+                    entry = (XF && items) ? items[first + prefix] : first + prefix;   // (a list: launch_shadow_culled)
+                    const size_t e = entry;
                     const float4 a = pool.shadowQ[2 * e], b = pool.shadowQ[2 * e + 1];
                     code = __float_as_uint(b.w);
                     o = mk3(a.x, a.y, a.z);
@@ -548,10 +576,35 @@ void launch_shadow(const DevScene& sc, const LaunchCfg& cfg, const PathPool& poo
     const uint32_t grid = need < (uint32_t)cfg.gridBlocks ? need : (uint32_t)cfg.gridBlocks;
     if (sc.has_xf)
         hipLaunchKernelGGL(shadow_kernel<true>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, pool, q, useTransmittance, cfg.spill,
-                           segq_chunk(n, grid * (TRAV_BLOCK / 64)));
+                           segq_chunk(n, grid * (TRAV_BLOCK / 64)), (const uint32_t*)nullptr);
+    else if (pool.cullShadows)
+        hipLaunchKernelGGL((shadow_kernel<false, true>), dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, pool, q, useTransmittance, cfg.spill,
+                           segq_chunk(n, grid * (TRAV_BLOCK / 64)), (const uint32_t*)nullptr);
     else
         hipLaunchKernelGGL(shadow_kernel<false>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, pool, q, useTransmittance, cfg.spill,
-                           segq_chunk(n, grid * (TRAV_BLOCK / 64)));
+                           segq_chunk(n, grid * (TRAV_BLOCK / 64)), (const uint32_t*)nullptr);
+}
+// The chains the lean shadow kernel set aside (pool.cullShadows, their number in pool.totals[5]) through the general
+// kernel. The host does not know the number: a one-wave kernel turns it into an identity queue over the list and resets it,
+// and a two-block grid drains that queue (a frame holds a few dozen such chains).
+__global__ void segq_identity_counted_kernel(SegQ q, uint32_t* count, uint32_t cap) {
+    const uint32_t l = threadIdx.x;
+    const uint32_t n = min(*count, cap);
+    const uint32_t lo = (uint32_t)(((unsigned long long)l * n) / QSEG);
+    q.ctl[SEGQ_PREFIX + l] = lo;
+    q.ctl[SEGQ_START + l] = lo;
+    q.ctl[SEGQ_COUNT + l * QSTRIDE] = 0u;
+    q.ctl[SEGQ_CURSOR + l * QSTRIDE] = 0u;
+    __syncthreads();
+    if (l == 63u) {
+        q.ctl[SEGQ_PREFIX + QSEG] = n;
+        *count = 0u;
+    }
+}
+void launch_shadow_culled(const DevScene& scGeneral, const LaunchCfg& cfg, const PathPool& pool, const SegQ& qList, int useTransmittance) {
+    hipLaunchKernelGGL(segq_identity_counted_kernel, dim3(1), dim3(64), 0, cfg.stream, qList, pool.totals + 5, RTX_CULL_CAP);
+    hipLaunchKernelGGL(shadow_kernel<true>, dim3(2), dim3(TRAV_BLOCK), 0, cfg.stream, scGeneral, pool, qList, useTransmittance, cfg.spill, 64u,
+                       (const uint32_t*)pool.cullShadows);
 }
 void launch_film(const PathPool& pool, const rtx_film& film, const int* pixels, uint32_t nPix, int S, int W, int H, int filterType,
                  float filterRadius, int resetZ, float4* samplesOut, int sBase, int sppTotal, float radianceClamp, int nLights,

@@ -27,6 +27,8 @@ struct DevPhotonMap {
     int maxPhotons;         // 30 / 50 / 100 (RayCaster.cpp:149-151)
 };
 
+#define RTX_CULL_CAP 65536u   // entries of PathPool::cullPaths / cullShadows (a 1080p x 128 spp frame holds about 60)
+
 struct PathPool {
     uint32_t capacity;      // slots
     // per slot
@@ -54,7 +56,13 @@ struct PathPool {
     uint32_t* sortKeysOut;
     uint32_t* sortItemsIn;
     uint32_t* sortItems;    // path slots in key order: the item list of the next extend launch
-    uint32_t* totals;       // [0] entries of the queue shade appended to, [1] entries of the shadow queue
+    uint32_t* totals;       // [0] entries of the queue shade appended to, [1] entries of the shadow queue,
+                            // [4] entries of cullPaths, [5] entries of cullShadows
+    // Box culls of the reference in scenes of world-space triangles (traverse.h ref_box_hit): the lean
+    // kernels trace without them; the few hits the reference would not have reached are found afterwards (shade_kernel,
+    // shadow_kernel) and handed to the general kernels. nullptr: not checked (RTX_AMD_BOX_CULLS=0, general scenes).
+    uint32_t* cullPaths;    // path slots whose vertex was not shaded: their ray is traced again by the general tail kernel
+    uint32_t* cullShadows;  // shadow queue entries whose chain is traced again by the general shadow kernel
     uint32_t* counters;     // scratch counters ([8] adaptive refinement list)
     // per pixel (full frame)
     int* pixels;            // pixel list of the current round (padded to 64 with -1)

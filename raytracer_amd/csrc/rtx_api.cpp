@@ -2,6 +2,7 @@
 #include "rtx_internal.h"
 #include "rtx_math.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 static thread_local std::string g_err;
@@ -131,6 +132,9 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
         if (o.flags & OBJ_XFMESH) d.has_xf = 1;   // selects the kernels that carry the object-space triangle test ...
     for (const TriRec& t : hs.tris)
         if (t.kind != 0u) d.has_xf = 1;           // ... and the Sphere / Plane test (any record that is not a world-space triangle)
+    // RTX_AMD_GENERAL_KERNELS=1: the general kernels for a scene of world-space triangles too. They repeat the reference's
+    // root and object box tests, which the lean kernels leave out: the switch measures what that omits
+    if (const char* e = std::getenv("RTX_AMD_GENERAL_KERNELS")) if (std::atoi(e) != 0) d.has_xf = 1;
     std::memcpy(d.bounds, hs.bounds, sizeof(d.bounds));
     s->nTris = hs.tris.size();
     s->nNodes = hs.nodes.size();

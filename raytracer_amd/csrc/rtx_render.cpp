@@ -31,6 +31,7 @@ struct PathPoolHost {
     // the pixel list of this rank's buckets, kept on the device between calls (building and uploading it costs the host
     // 16 ms per 1080p frame, during which the GPU waits): valid while baseKey = {W, H, tile, rank, world} matches
     int* pixelsBase = nullptr;    // in allocs; never written by the adaptive rounds
+    SegQ qCull{};                 // in allocs: control words of the queue over PathPool::cullShadows
     int baseKey[5] = {0, 0, 0, 0, 0};
     uint32_t baseN = 0;
     size_t baseValid = 0;
@@ -125,6 +126,9 @@ static int ensure_pool(rtx_scene* s, uint32_t slots, size_t framePixels, size_t 
     PA(qB.ctl, SEGQ_WORDS);
     PA(qS.ctl, SEGQ_WORDS);
     PA(totals, 16);
+    PA(cullPaths, RTX_CULL_CAP);
+    PA(cullShadows, RTX_CULL_CAP);
+    if ((rc = pool_alloc(ph, &ph->qCull.ctl, SEGQ_WORDS)) != RTX_OK) return rc;
     PA(counters, 64);
     PA(pixels, ph->framePixels + 64);
     PA(pixelsNext, ph->framePixels + 64);
@@ -342,6 +346,8 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
         RTX_HIP(hipMemcpyAsync(pool.pixels, list.data(), (size_t)nPix * sizeof(int), hipMemcpyHostToDevice, st));
     if (!spec) launch_stats_clear(pool, (uint32_t)((size_t)W * H), st);
     RTX_HIP(hipMemsetAsync(pool.rayCounters, 0, 8 * sizeof(unsigned long long), st));
+    RTX_HIP(hipMemsetAsync(pool.totals, 0, 16 * sizeof(uint32_t), st));
+    RTX_HIP(hipMemsetAsync(ph->qCull.ctl, 0, SEGQ_WORDS * sizeof(uint32_t), st));
     if (s->cfg.counting) RTX_HIP(hipMemsetAsync(s->cfg.counters, 0, 3 * sizeof(unsigned long long), st));
     // queue counters are left at zero by every scan; a cancelled or failed call may have left some behind
     RTX_HIP(hipMemsetAsync(pool.qA.ctl, 0, SEGQ_WORDS * sizeof(uint32_t), st));
@@ -394,6 +400,16 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     if (const char* e = std::getenv("RTX_AMD_SYNC_EVERY")) syncEvery = std::max(1, std::atoi(e));
     if (s->cfg.counting || sortRays || sortShade) syncEvery = 1;
     unsigned long long handedOver = 0;   // paths counted by the device sums but not traced by an extend launch (tail kernel, bounce limit)
+    // Scenes of world-space triangles run the lean kernels, which leave out the reference's root and object box tests
+    // (traverse.h ref_box_hit); with `culls` the shade and shadow kernels find the hits those tests would have removed - about
+    // 2 in 10^7 samples of the C3 frame - and the general kernels trace them again: the vertex through the tail kernel, the
+    // shadow chain through a second, tiny shadow launch. Opt-in (RTX_AMD_BOX_CULLS=1): the checks cost 8 % of the C3 frame
+    // (shadow 162 -> 221 ms: an object id and a box to fetch at the end of every blocked hop), the general kernels 24 %.
+    bool culls = false;
+    if (const char* e = std::getenv("RTX_AMD_BOX_CULLS")) culls = std::atoi(e) != 0 && !legacy && !s->dev.has_xf && syncEvery == 1 && !s->cfg.counting;
+    if (!culls) pool.cullPaths = pool.cullShadows = nullptr;
+    DevScene devGeneral = s->dev;
+    if (culls) devGeneral.has_xf = 1;   // tail kernel and re-traces: the instantiation that repeats the box tests
     s->cancel.store(0);
     PassTimers tm{ph};
     int* curPixels = spec ? pool.pixels : ph->pixelsBase;
@@ -473,7 +489,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 // launches are large enough not to care; bounds that have come near the tail kernel's regime are checked too
                 const bool lastBounce = bounce + 1 >= rp->max_bounces;
                 const bool syncNow = syncEvery == 1 || lastBounce || n > (8u << 20) || (bounce + 1) % syncEvery == 0;
-                uint32_t cnt[2] = {n, (uint32_t)std::min<unsigned long long>((unsigned long long)n * shadowMult, 0xFFFFFFFFull)};   // upper bounds
+                uint32_t cnt[6] = {n, (uint32_t)std::min<unsigned long long>((unsigned long long)n * shadowMult, 0xFFFFFFFFull), 0, 0, 0, 0};   // upper bounds
                 if (syncNow) {
                     RTX_HIP(hipMemcpyAsync(cnt, pool.totals, sizeof(cnt), hipMemcpyDeviceToHost, st));
                     RTX_HIP(hipStreamSynchronize(st));
@@ -491,11 +507,28 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                     tm.nextItems = cnt[1];
                     tm.begin(1, sst);
                     launch_shadow(s->dev, side ? sideCfg : s->cfg, pool, pool.qS, cnt[1], (bounce <= 8 ? 1 : 0) | shadowFlags);   // useTransmittance (RayCaster.cpp:454)
+                    if (culls) launch_shadow_culled(devGeneral, side ? sideCfg : s->cfg, pool, ph->qCull, (bounce <= 8 ? 1 : 0) | shadowFlags);
                     tm.end(sst);
                 }
                 if (side) {
                     RTX_HIP(hipEventRecord(ph->sideDone, ph->sideStream));
                     sidePending = true;
+                }
+                if (culls && cnt[4] > 0) {
+                    // vertices of this bounce whose hit the reference would not have reached: their paths go on in the general
+                    // tail kernel, from this bounce's ray (still in pool.rays) to their ends
+                    const uint32_t nC = std::min<uint32_t>(cnt[4], RTX_CULL_CAP);
+                    // (the transmittances of the previous bounce, which the tail kernel's resolve reads, were waited for in front
+                    // of this bounce's shade launch; this bounce's shadow launch holds no segment of these paths)
+                    launch_segq_identity(s->cfg.identQ, nC, st);
+                    tm.nextItems = nC;
+                    tm.begin(2, st);
+                    launch_tail(devGeneral, s->cfg, dc, pool, pm, s->cfg.identQ, pool.cullPaths, nC, bounce, rp->max_bounces, rp->seed, sBase, Sp, curPixels,
+                                (s->hasMicrofacet || s->hasPhong) ? 1 : 0, pm.n > 0 ? 1 : 0);
+                    tm.end(st);
+                    RTX_HIP(hipMemsetAsync(pool.totals + 4, 0, sizeof(uint32_t), st));
+                    if (bounce == 0) out.rays_primary -= nC;   // traced again (and counted) by the tail kernel
+                    else out.rays_bounce -= nC;
                 }
                 std::swap(qin, qout);
                 std::swap(sqIn, sqOut);
@@ -519,7 +552,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                     }
                     tm.nextItems = n;
                     tm.begin(2, st);
-                    launch_tail(s->dev, s->cfg, dc, pool, pm, sqIn, qin, n, bounce + 1, rp->max_bounces, rp->seed, sBase, Sp, curPixels,
+                    launch_tail(devGeneral, s->cfg, dc, pool, pm, sqIn, qin, n, bounce + 1, rp->max_bounces, rp->seed, sBase, Sp, curPixels,
                                 (s->hasMicrofacet || s->hasPhong) ? 1 : 0, pm.n > 0 ? 1 : 0);
                     tm.end(st);
                     if (syncEvery > 1) handedOver += n;   // their first rays are the tail kernel's (rayCounters[1])

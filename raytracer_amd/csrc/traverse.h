@@ -90,6 +90,32 @@ __device__ __forceinline__ bool ref_box_hit(const float* box, float px, float py
     return tmax >= 0.0f && tmin <= t_max;
 }
 
+// Is point p (the hit, a distance t along a ray) inside `box` by a margin that is large against the rounding of
+// ref_box_hit - 0.1 % of the box's extent plus 1e-5 of the magnitudes involved, per axis? Then every slab is entered
+// before and left after the hit by far more than an ulp of the slab distances, and ref_box_hit accepts; no division.
+__device__ __forceinline__ bool well_inside_box(const float* box, float px, float py, float pz, float t) {
+    const float q[3] = {px, py, pz};
+    bool in = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float eps = 1e-3f * (box[3 + i] - box[i]) + 1e-5f * (fabsf(q[i]) + fabsf(t));
+        in = in && q[i] > box[i] + eps && q[i] < box[3 + i] - eps;
+    }
+    return in;
+}
+// Does the reference reach triangle `slot` of a scene of world-space triangles with ray r, which hits it at t? (the
+// root's box, then the object's own: IntersectNodeAdapter.h:30-32, :63-75). The exact tests run only for hits near a
+// face of one of the two boxes (flat objects, rims, the walls of the scene).
+__device__ __forceinline__ bool ref_reaches_triangle(const DevScene& sc, const RayT& r, int slot, float t) {
+    const float px = r.ox + r.dx * t, py = r.oy + r.dy * t, pz = r.oz + r.dz * t;
+    const uint32_t obj = sc.tris[slot].obj & TRI_OBJ_MASK;
+    const float* obox = sc.objXf[obj].box;
+    const bool sure = t < 1e6f && r.tmax > t * 1.001f && well_inside_box(sc.bounds, px, py, pz, t) && well_inside_box(obox, px, py, pz, t);
+    if (sure) return true;
+    if (!ref_box_hit(sc.bounds, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.tmax)) return false;
+    return ref_box_hit(obox, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.tmax);
+}
+
 // One triangle, objects.cpp:140-171 and :190-191. The arithmetic order is the reference's; contraction is off so
 // that u, v and t are bit-identical to an fp32 CPU evaluation. r is the ray in the triangle's own space.
 __device__ __forceinline__ void test_triangle(const float4 a, const float4 b, const float4 c, const RayT& r, int hitSide,
