@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
         // a hit that the reference's box tests would have culled (lean extend kernel: not checked there): the vertex is left
         // alone and the path goes to the general tail kernel, which traces its ray again (rtx_render.cpp)
         bool culled = false;
-        if (pool.cullPaths && hitSlot >= 0 && !ref_reaches_triangle(sc, ray, hitSlot, hv.x)) {
+        if (pool.cullPaths && hitSlot >= 0 && !ref_reaches_triangle<false>(sc, ray, hitSlot, hv.x)) {
             const uint32_t k = atomicAdd(&pool.totals[4], 1u);
             if (k < RTX_CULL_CAP) {
                 pool.cullPaths[k] = slot;
@@ -236,7 +236,9 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
             // lean kernel: a hop that ends on a hit the reference's box tests would have culled (not checked on the way: see
             // ref_box_hit) is not resolved here - the whole chain is traced again by the general kernel (launch_shadow_culled)
             bool culledHop = false;
-            if (!XF && CULL && fin && mode != 3 && pool.cullShadows && s.best.slot >= 0 && !ref_reaches_triangle(scArg, s.r, s.best.slot, s.best.t)) {
+            // (measured: the objects' boxes in LDS and the best hit's object word kept in a register - no memory to wait for
+            // here - cost more in the traversal loop than they save: 317 ms per C3 frame against 191)
+            if (!XF && CULL && fin && mode != 3 && pool.cullShadows && s.best.slot >= 0 && !ref_reaches_triangle<true>(scArg, s.r, s.best.slot, s.best.t)) {
                 const uint32_t k = atomicAdd(&pool.totals[5], 1u);
                 if (k < RTX_CULL_CAP) {
                     pool.cullShadows[k] = entry;

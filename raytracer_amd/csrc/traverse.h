@@ -103,17 +103,32 @@ __device__ __forceinline__ bool well_inside_box(const float* box, float px, floa
     }
     return in;
 }
+// (out of line for the shadow kernel, whose loop then keeps its registers: 221 -> 191 ms per C3 frame; a call inside the
+// shade kernel costs it 100 ms instead; reached for hits near a box face only)
+__device__ __noinline__ bool ref_reaches_exact(const float* rootBox, const float* objBox, float ox, float oy, float oz, float dx, float dy, float dz,
+                                               float tmax) {
+    if (!ref_box_hit(rootBox, ox, oy, oz, dx, dy, dz, tmax)) return false;
+    return ref_box_hit(objBox, ox, oy, oz, dx, dy, dz, tmax);
+}
 // Does the reference reach triangle `slot` of a scene of world-space triangles with ray r, which hits it at t? (the
 // root's box, then the object's own: IntersectNodeAdapter.h:30-32, :63-75). The exact tests run only for hits near a
 // face of one of the two boxes (flat objects, rims, the walls of the scene).
-__device__ __forceinline__ bool ref_reaches_triangle(const DevScene& sc, const RayT& r, int slot, float t) {
+template <bool OUTLINE>
+__device__ __forceinline__ bool ref_reaches_box(const DevScene& sc, const RayT& r, const float* obox, float t) {
     const float px = r.ox + r.dx * t, py = r.oy + r.dy * t, pz = r.oz + r.dz * t;
-    const uint32_t obj = sc.tris[slot].obj & TRI_OBJ_MASK;
-    const float* obox = sc.objXf[obj].box;
     const bool sure = t < 1e6f && r.tmax > t * 1.001f && well_inside_box(sc.bounds, px, py, pz, t) && well_inside_box(obox, px, py, pz, t);
     if (sure) return true;
+    if (OUTLINE) return ref_reaches_exact(sc.bounds, obox, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.tmax);
     if (!ref_box_hit(sc.bounds, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.tmax)) return false;
     return ref_box_hit(obox, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.tmax);
+}
+template <bool OUTLINE>
+__device__ __forceinline__ bool ref_reaches_triangle(const DevScene& sc, const RayT& r, int slot, float t) {
+    const uint32_t obj = sc.tris[slot].obj & TRI_OBJ_MASK;
+    float ob[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ob[i] = sc.objXf[obj].box[i];
+    return ref_reaches_box<OUTLINE>(sc, r, ob, t);
 }
 
 // One triangle, objects.cpp:140-171 and :190-191. The arithmetic order is the reference's; contraction is off so

@@ -149,6 +149,7 @@ def test_reference_box_culls_full_size(full, full_oracle, monkeypatch):
     sd, gs, cam = full
     spp = 4
     rp = render_params(spp_min=spp, max_bounces=64)
+    monkeypatch.setenv("RTX_AMD_BOX_CULLS", "0")
     lean, st0 = gs.render_samples(cam, rp)
     monkeypatch.setenv("RTX_AMD_BOX_CULLS", "1")
     exact, st1 = gs.render_samples(cam, rp)
