@@ -399,7 +399,7 @@ int rtx_trace_closest_device(rtx_scene* s, const void* rays_dev, size_t n, int h
     if (n && (!rays_dev || !hit4_dev)) return rtx_fail(RTX_ERR_INVALID, "NULL ray/hit buffer");
     LaunchCfg cfg = s->cfg;
     cfg.stream = (hipStream_t)stream;
-    launch_extend(s->dev, cfg, (const float4*)rays_dev, (uint32_t)n, hit_side, with_lights, (float4*)hit4_dev);
+    launch_extend(rtx_traversal_scene(s), cfg, (const float4*)rays_dev, (uint32_t)n, hit_side, with_lights, (float4*)hit4_dev);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }
@@ -438,7 +438,7 @@ int rtx_trace_visibility(rtx_scene* s, const rtx_ray* rays, const float* normals
     }
     RTX_HIP(hipMemcpy(s->rays.p, rays, n * sizeof(rtx_ray), hipMemcpyHostToDevice));
     RTX_HIP(hipMemcpy(s->aux.p, n4.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-    launch_visibility(s->dev, s->cfg, (const float4*)s->rays.p, (const float4*)s->aux.p, (uint32_t)n, use_transmittance,
+    launch_visibility(rtx_traversal_scene(s), s->cfg, (const float4*)s->rays.p, (const float4*)s->aux.p, (uint32_t)n, use_transmittance,
                       (float*)s->aux2.p, nullptr);
     RTX_HIP(hipGetLastError());
     RTX_HIP(hipMemcpy(vis, s->aux2.p, n * sizeof(float), hipMemcpyDeviceToHost));

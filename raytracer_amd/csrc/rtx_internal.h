@@ -1,5 +1,6 @@
 // Internal host-side state behind the opaque C-ABI handles.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <string>
@@ -43,3 +44,15 @@ struct rtx_scene {
 };
 
 int make_dev_camera(const rtx_camera* cam, DevCamera& out);
+
+// The scene descriptor a traversal kernel is launched with outside the wavefront path loop (ray queries, photon emission,
+// the legacy integrator): with RTX_AMD_BOX_CULLS=1 a scene of world-space triangles runs the general instantiation there,
+// which repeats the reference's root and object box tests (traverse.h ref_box_hit). The path loop
+// itself keeps its lean kernels and checks after the fact (rtx_render.cpp).
+inline DevScene rtx_traversal_scene(const rtx_scene* s) {
+    DevScene d = s->dev;
+    if (!d.has_xf)
+        if (const char* e = std::getenv("RTX_AMD_BOX_CULLS"))
+            if (std::atoi(e) != 0) d.has_xf = 1;
+    return d;
+}

@@ -177,7 +177,7 @@ int rtx_photon_build(rtx_scene* s, const rtx_photon_params* pp, rtx_photons** ou
     (void)hipEventCreate(&e1);
     (void)hipMemset(p->counts, 0, 16 * sizeof(uint32_t));
     (void)hipEventRecord(e0, nullptr);
-    launch_photon_emit(s->dev, s->cfg, pp->num_photons, pp->first_photon, stride, pp->max_bounces, pp->seed, p->set[0].raw, cap,
+    launch_photon_emit(rtx_traversal_scene(s), s->cfg, pp->num_photons, pp->first_photon, stride, pp->max_bounces, pp->seed, p->set[0].raw, cap,
                        p->set[1].raw, cap, p->counts);
     (void)hipEventRecord(e1, nullptr);
     uint32_t cnt[4] = {0, 0, 0, 0};

@@ -441,11 +441,11 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 // primary hits by the extend kernel, then the whole recursion of every sample in one kernel
                 out.rays_primary += n;
                 tm.begin(0, st);
-                launch_extend_queue(s->dev, s->cfg, pool.rays, sqIn, qin, n, RTX_HIT_FRONT_AND_BACK, 1, pool.hits);
+                launch_extend_queue(rtx_traversal_scene(s), s->cfg, pool.rays, sqIn, qin, n, RTX_HIT_FRONT_AND_BACK, 1, pool.hits);
                 tm.end(st);
                 out.extend_launches++;
                 tm.begin(2, st);
-                launch_legacy(s->dev, s->cfg, dc, pool, pmGlobal, pm, sqIn, qin, n, rp->seed, sBase, Sp, curPixels,
+                launch_legacy(rtx_traversal_scene(s), s->cfg, dc, pool, pmGlobal, pm, sqIn, qin, n, rp->seed, sBase, Sp, curPixels,
                               (!s->hasMicrofacet && !s->hasPhong) ? 1 : 0, ph->legacyState);
                 tm.end(st);
                 RTX_HIP(hipStreamSynchronize(st));   // one pass at a time, so that rtx_cancel is seen between passes
@@ -693,7 +693,7 @@ int rtx_trace_secondary(rtx_scene* s, const rtx_photons* photons, const rtx_shad
     if ((rc = s->aux.ensure(n * 3 * sizeof(float))) != RTX_OK) return rc;
     if ((rc = s->hits.ensure(n * sizeof(float4))) != RTX_OK) return rc;
     RTX_HIP(hipMemcpy(s->aux.p, dirs, n * 3 * sizeof(float), hipMemcpyHostToDevice));
-    launch_legacy_secondary(s->dev, s->cfg, pmGlobal, pmCaustic, *at, (const float*)s->aux.p, (uint32_t)n, recursive, child, seed,
+    launch_legacy_secondary(rtx_traversal_scene(s), s->cfg, pmGlobal, pmCaustic, *at, (const float*)s->aux.p, (uint32_t)n, recursive, child, seed,
                             (float4*)s->hits.p);
     RTX_HIP(hipGetLastError());
     RTX_HIP(hipMemcpy(color_dist, s->hits.p, n * sizeof(float4), hipMemcpyDeviceToHost));
