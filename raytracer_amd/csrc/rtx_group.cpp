@@ -272,8 +272,11 @@ static int group_render_adaptive(rtx_group* g, const rtx_camera* cam, const rtx_
         base += nS;
         if (!more) break;
         // ---- on member 0's device: collect, test, deal ----
-        int prev = 0;
-        (void)hipGetDevice(&prev);
+        struct DeviceGuard {   // the caller's device comes back on every way out of this block
+            int prev = 0;
+            DeviceGuard() { (void)hipGetDevice(&prev); }
+            ~DeviceGuard() { (void)hipSetDevice(prev); }
+        } guard;
         RTX_HIP(hipSetDevice(g->m[0].device));
         for (int i = 1; i < n; ++i) {
             if (mine[i].empty()) continue;
@@ -284,7 +287,7 @@ static int group_render_adaptive(rtx_group* g, const rtx_camera* cam, const rtx_
             RTX_HIP(hipDeviceSynchronize());   // listDev is reused by the next member
         }
         const int64_t nRef = rtx_refine_list(&g->m[0].pstats, W, H, params->ci_halfwidth, params->spp_max, refine.data(), refine.size());
-        (void)hipSetDevice(prev);
+        (void)hipSetDevice(guard.prev);
         if (nRef < 0) return (int)nRef;
         if (nRef == 0) break;
         weight.assign((size_t)nbx * nby, 0);
