@@ -139,6 +139,8 @@ __device__ __forceinline__ uint32_t ray_sort_key(const DevScene& sc, const float
 #ifndef SHADE_WAVES_PER_EU
 #define SHADE_WAVES_PER_EU 3
 #endif
+// (the instantiations with the microfacet / Phong forms compiled in spill 36-74 registers at three waves, yet two waves
+// are slower: C3 scene through them, 32 spp: 96-105 ms against 110-112; the plain form: 91)
 template <bool MICRO, bool PHOT, bool PHONG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES_PER_EU))) void shade_kernel(DevScene sc, DevCamera cam, PathPool pool, DevPhotonMap pm,
                                                     SegQ qIn, const uint32_t* __restrict__ queueIn, uint32_t n, int bounce,

@@ -67,10 +67,16 @@ void launch_segq_identity(const SegQ& q, uint32_t n, hipStream_t stream) {
 #ifndef EXTEND_WAVES_PER_EU
 #define EXTEND_WAVES_PER_EU 6
 #endif
+// the general instantiation (XF: object-space triangles, Sphere / Plane, the reference's box tests) needs more registers:
+// at six waves it spills 43 of them inside the loop - C3 scene through the general kernels, 32 spp: extend 211 / 153 / 125 /
+// 125 ms at 6 / 5 / 4 / 3 waves per SIMD (the lean kernel: 82 ms)
+#ifndef EXTEND_WAVES_PER_EU_GENERAL
+#define EXTEND_WAVES_PER_EU_GENERAL 4
+#endif
 // BOTH: hitSide is RTX_HIT_FRONT_AND_BACK (every ray of the render loop): the side test of objects.cpp:175-191 - a normalised
 // geometric normal per candidate - is then not compiled into the leaf step (19 ms of the C3 frame's extend time)
 template <bool COUNT, bool XF, bool BOTH>
-__global__ __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(EXTEND_WAVES_PER_EU))) void extend_kernel(DevScene scArg, const float4* __restrict__ rays, SegQ q,
+__global__ __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(XF ? EXTEND_WAVES_PER_EU_GENERAL : EXTEND_WAVES_PER_EU))) void extend_kernel(DevScene scArg, const float4* __restrict__ rays, SegQ q,
                                                             const uint32_t* __restrict__ items, int hitSide, int withLights,
                                                             float4* __restrict__ hits, uint2* spill, unsigned long long* counters,
                                                             uint32_t chunk) {

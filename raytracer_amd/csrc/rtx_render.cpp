@@ -399,6 +399,8 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     int syncEvery = 1;
     if (const char* e = std::getenv("RTX_AMD_SYNC_EVERY")) syncEvery = std::max(1, std::atoi(e));
     if (s->cfg.counting || sortRays || sortShade) syncEvery = 1;
+    int shadeKinds = (s->hasMicrofacet ? 1 : 0) | (s->hasPhong ? 2 : 0);   // which forms of the shade kernel the scene needs
+    if (const char* e = std::getenv("RTX_AMD_SHADE_KINDS")) shadeKinds |= std::atoi(e) & 3;   // (measurements: a more general form than needed)
     unsigned long long handedOver = 0;   // paths counted by the device sums but not traced by an extend launch (tail kernel, bounce limit)
     // Scenes of world-space triangles run the lean kernels, which leave out the reference's root and object box tests
     // (traverse.h ref_box_hit); with `culls` the shade and shadow kernels find the hits those tests would have removed - about
@@ -481,7 +483,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                     shadeQ = s->cfg.identQ;
                 }
                 const uint32_t gridShade = launch_shade(s->dev, dc, pool, pm, shadeQ, shadeItems, n, bounce, rp->max_bounces, rp->seed, sBase, Sp,
-                                                        curPixels, sqOut, qout, pool.qS, (s->hasMicrofacet ? 1 : 0) | (s->hasPhong ? 2 : 0), st, sortRays ? pool.sortKeys : nullptr);
+                                                        curPixels, sqOut, qout, pool.qS, shadeKinds, st, sortRays ? pool.sortKeys : nullptr);
                 tm.end(st);
                 launch_segq_scan2(sqOut, gridShade, 1, pool.qS, gridShade, shadowMult, 256, pool.totals, st,
                                   syncEvery > 1 ? pool.rayCounters + 2 : nullptr);
