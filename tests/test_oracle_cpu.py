@@ -56,6 +56,37 @@ def test_box_slab_against_float64():
     assert (res == g["hit"]).all()  # regression vector
 
 
+def test_hits_well_inside_a_box_pass_the_reference_box_test():
+    """The box-cull check of RTX_AMD_BOX_CULLS (raytracer_amd/csrc/traverse.h: well_inside_box, ref_reaches_triangle)
+    accepts a hit without running the reference's slab test when the hit point lies inside the box by a margin of
+    1e-3 of the extent + 1e-5 (|p| + t) per axis. That shortcut must never accept what scene_box.cpp:8-46 rejects: two
+    million random boxes (flat to room-sized), rays from every direction and distance, segment ends just behind the hit."""
+    rng = np.random.default_rng(2024)
+    n = 2_000_000
+    f = np.float32
+    ext = (10.0 ** rng.uniform(-4, 1, (n, 3))).astype(f)
+    ctr = rng.uniform(-5, 5, (n, 3)).astype(f)
+    lo, hi = (ctr - ext * f(0.5)).astype(f), (ctr + ext * f(0.5)).astype(f)
+    p = (lo + (hi - lo) * rng.uniform(0, 1, (n, 3)).astype(f)).astype(f)
+    d = rng.normal(size=(n, 3))
+    d[rng.random(n) < 0.1, rng.integers(0, 3)] = 0.0                       # axis-parallel rays too
+    d = (d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)).astype(f)
+    t = (10.0 ** rng.uniform(-3, 2.5, n)).astype(f)
+    o = (p - d * t[:, None]).astype(f)
+    tmax = np.where(rng.random(n) < 0.5, f(1e30), t * rng.uniform(1.0011, 2.0, n).astype(f)).astype(f)
+    q = (o + d * t[:, None]).astype(f)                                     # the hit point as the kernel forms it
+    eps = (f(1e-3) * (hi - lo) + f(1e-5) * (np.abs(q) + np.abs(t)[:, None])).astype(f)
+    sure = ((q > lo + eps) & (q < hi - eps)).all(1) & (t < f(1e6)) & (tmax > t * f(1.001))
+    assert sure.sum() > 100_000
+    rays = np.zeros(n, ray_dt)
+    rays["o"], rays["d"], rays["tmax"] = o, d, tmax
+    boxes = np.ascontiguousarray(np.concatenate([lo, hi], 1), f)
+    res = np.zeros(n, np.uint8)
+    lib().orc_box_intersect(boxes.ctypes.data_as(C.c_void_p), rays.ctypes.data_as(C.c_void_p), C.c_size_t(n), res.ctypes.data_as(C.c_void_p))
+    assert res[sure].all(), int((~res[sure].astype(bool)).sum())
+    assert not res.all()                                                   # the unsure rest does hold rejected hits (thin boxes, rims)
+
+
 def test_triangle_hits_against_float64():
     """objects.cpp:140-171: t/u/v of the oracle against a float64 Moller-Trumbore on the same triangle."""
     sd, cam = synth.single_mesh_scene("teapots", 0.02)
