@@ -457,6 +457,11 @@ __device__ __forceinline__ bool trav_verify(TravState& s, const SC& sc) {
     if (!SC::kXF) return true;
     if (s.best.slot < 0) return true;
     const RayT r = s.r;
+    const uint32_t kind = sc.tris[s.best.slot].kind, obj = sc.tris[s.best.slot].obj & TRI_OBJ_MASK;
+    if (kind == 0u) {   // world-space triangle hit well inside both boxes: both tests pass (well_inside_box), no divisions
+        const float t = s.best.t, px = r.ox + r.dx * t, py = r.oy + r.dy * t, pz = r.oz + r.dz * t;
+        if (t < 1e6f && r.tmax > t * 1.001f && well_inside_box(sc.bounds, px, py, pz, t) && well_inside_box(sc.objXf[obj].box, px, py, pz, t)) return true;
+    }
     if (!ref_box_hit(sc.bounds, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.tmax)) {
         s.best.t = r.tmax;
         s.best.u = 0.0f;
@@ -465,7 +470,6 @@ __device__ __forceinline__ bool trav_verify(TravState& s, const SC& sc) {
         s.bestPrim = 0xFFFFFFFFu;
         return true;
     }
-    const uint32_t kind = sc.tris[s.best.slot].kind, obj = sc.tris[s.best.slot].obj & TRI_OBJ_MASK;
     if (kind != 0u && kind != RTX_KIND_XFTRI) return true;   // Sphere / Plane: tested on the way in (test_analytic)
     float p[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
     if (kind == RTX_KIND_XFTRI) ray_to_object(sc, obj, r, p, d);
