@@ -405,8 +405,8 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     // Scenes of world-space triangles run the lean kernels, which leave out the reference's root and object box tests
     // (traverse.h ref_box_hit); with `culls` the shade and shadow kernels find the hits those tests would have removed - about
     // 2 in 10^7 samples of the C3 frame - and the general kernels trace them again: the vertex through the tail kernel, the
-    // shadow chain through a second, tiny shadow launch. Opt-in (RTX_AMD_BOX_CULLS=1): the checks cost 8 % of the C3 frame
-    // (shadow 162 -> 221 ms: an object id and a box to fetch at the end of every blocked hop), the general kernels 24 %.
+    // shadow chain through a second, tiny shadow launch. Opt-in (RTX_AMD_BOX_CULLS=1): the checks cost 4 % of the C3 frame
+    // (shadow 162 -> 194 ms: an object id and a box to fetch at the end of every blocked hop), the general kernels 20 %.
     bool culls = false;
     if (const char* e = std::getenv("RTX_AMD_BOX_CULLS")) culls = std::atoi(e) != 0 && !legacy && !s->dev.has_xf && syncEvery == 1 && !s->cfg.counting;
     if (!culls) pool.cullPaths = pool.cullShadows = nullptr;
