@@ -154,7 +154,7 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
-    agg = dict(rays=0, ext_rays=0, extend_ms=0.0, shadow_ms=0.0, shade_ms=0.0, launches=0, shadow_rays=0)
+    agg = dict(rays=0, ext_rays=0, extend_ms=0.0, shadow_ms=0.0, shade_ms=0.0, nee_ms=0.0, launches=0, shadow_rays=0)
     for _ in range(a.steps):
         st = step()
         agg["rays"] += st["rays_primary"] + st["rays_bounce"] + st["rays_shadow"]
@@ -163,6 +163,7 @@ def main():
         agg["extend_ms"] += st["extend_ms"]
         agg["shadow_ms"] += st["shadow_ms"]
         agg["shade_ms"] += st["shade_ms"]
+        agg["nee_ms"] += st["nee_ms"]
         agg["launches"] += st["extend_launches"]
     sync()
     dt = time.perf_counter() - t0
@@ -209,7 +210,7 @@ def main():
                          "extend_Mrays_s": agg["ext_rays"] / max(1e-9, agg["extend_ms"]) / 1e3,
                          "limiter": measured_limiter()},
             "kernel_ms_per_frame_rank0": {"extend": agg["extend_ms"] / a.steps, "shadow": agg["shadow_ms"] / a.steps,
-                                          "shade": agg["shade_ms"] / a.steps},
+                                          "shade": agg["shade_ms"] / a.steps, "nee": agg["nee_ms"] / a.steps},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, cam, a)

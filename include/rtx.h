@@ -219,6 +219,14 @@ typedef struct {
     uint64_t extend_launches;
     uint64_t rays_extend;          /* primary + bounce rays traced by the extend launches that extend_ms times
                                     * (bounce rays of the tail / legacy kernels are in rays_bounce only)       */
+    /* what the bench prices shade_kernel / nee_kernel / shadow_kernel with (path mode) */
+    uint64_t shade_launches;
+    uint64_t vertices;             /* path vertices shaded by the shade launches that shade_ms times            */
+    uint64_t shadow_launches;
+    uint64_t shadow_segments;      /* NEE segments handed to the shadow launches that shadow_ms times           */
+    uint64_t shadow_nodes;         /* nodes visited / triangles tested by those launches; only with counters    */
+    uint64_t shadow_tris;
+    double   nee_ms;               /* the nee_kernel launches alone (also contained in shade_ms)                */
 } rtx_stats;
 
 /* Photon mapping (PhotonMapBuilder.h:46-54). */

@@ -101,7 +101,9 @@ class Stats(C.Structure):
                 ("rays_photon", C.c_uint64), ("paths", C.c_uint64), ("nodes_visited", C.c_uint64),
                 ("tris_tested", C.c_uint64), ("extend_ms", C.c_double), ("shadow_ms", C.c_double),
                 ("shade_ms", C.c_double), ("total_ms", C.c_double), ("extend_launches", C.c_uint64),
-                ("rays_extend", C.c_uint64)]
+                ("rays_extend", C.c_uint64), ("shade_launches", C.c_uint64), ("vertices", C.c_uint64),
+                ("shadow_launches", C.c_uint64), ("shadow_segments", C.c_uint64), ("shadow_nodes", C.c_uint64),
+                ("shadow_tris", C.c_uint64), ("nee_ms", C.c_double)]
 
 
 class PhotonParams(C.Structure):

@@ -58,6 +58,8 @@ struct PhongCtx {
     float alpha, ior;
     // lobe terms shared by sampling and evaluation (Shading.cpp:282-300 == :535-546)
     f3 fresnelRef, transColor, specColor;
+    f3 krf;       // kr + fresnelRef: the colour of the reflection lobe before its clamp (:290, :541)
+    bool krPos;   // max(kr) > 0 (:640)
 };
 
 // Shading.cpp:227-278 — built ONCE per hit (the reference rebuilds it for every GenerateSample/GetSampleInfo call)
@@ -100,6 +102,8 @@ __device__ __forceinline__ PhongCtx build_phong_ctx(const DevScene& sc, const De
     c.specColor = c.ks;
     if (max3c(c.kr) > 0.0f) c.specColor = mk3(0.0f);
     c.specColor = clamp_max3(c.specColor, 1.0f);
+    c.krf = c.kr + c.fresnelRef;
+    c.krPos = max3c(c.kr) > 0.0f;
     return c;
 }
 
@@ -108,7 +112,7 @@ __device__ __forceinline__ bool sample_phong_blinn(const PhongCtx& ctx, bool pho
     set_void(si);
     const float pd = luma1(ctx.kd);
     const float ps = luma1(ctx.specColor);
-    const float pr = luma1(ctx.kr + ctx.fresnelRef);
+    const float pr = luma1(ctx.krf);
     const float pt = luma1(ctx.transColor);
     const float total = pd + ps + pr + pt;
     if (total <= 0.0f) return false;
@@ -138,7 +142,7 @@ __device__ __forceinline__ bool sample_phong_blinn(const PhongCtx& ctx, bool pho
         f3 color = ctx.specColor;
         float pl = ps;
         if (!specLobe) {
-            color = clamp_max3(ctx.kr + ctx.fresnelRef, 1.0f);
+            color = clamp_max3(ctx.krf, 1.0f);
             pl = pr;
         }
         const float phi = 2.0f * PI_F * u1;
@@ -265,7 +269,7 @@ __device__ __forceinline__ void evaluate_phong_blinn(const PhongCtx& ctx, bool p
     int lobe = LOBE_NONE;
 
     if (cosN > 0.0f) {
-        const float pr = luma1(ctx.kr + ctx.fresnelRef);
+        const float pr = luma1(ctx.krf);
         const float total = pd + ps + pr + pt;
         if (total <= 0.0f) return;
         const float pdfDiff = pd > 0.0f ? (cosN / PI_F) * (pd / total) : 0.0f;
@@ -278,7 +282,7 @@ __device__ __forceinline__ void evaluate_phong_blinn(const PhongCtx& ctx, bool p
         if (phong) {
             const float cosR = fmaxf(0.0f, dot3(ctx.R, dir));
             if (pr > 0.0f && cosR > 0.0f) {
-                const f3 reflColor = clamp_max3(ctx.kr + ctx.fresnelRef, 1.0f);
+                const f3 reflColor = clamp_max3(ctx.krf, 1.0f);
                 pdfRefl = ((a + 1.0f) / (2.0f * PI_F)) * rtx_powf(cosR, a);
                 pdfRefl *= pr / total;
                 fRefl = reflColor * ((a + 2.0f) / (2.0f * PI_F)) * rtx_powf(cosR, a);
@@ -297,7 +301,7 @@ __device__ __forceinline__ void evaluate_phong_blinn(const PhongCtx& ctx, bool p
             if (NoH > 0.0f && VoH > 1e-6f) {
                 const float powNoH = rtx_powf(NoH, a);
                 if (pr > 0.0f) {
-                    const f3 reflColor = clamp_max3(ctx.kr + ctx.fresnelRef, 1.0f);
+                    const f3 reflColor = clamp_max3(ctx.krf, 1.0f);
                     const float pdfH = ((a + 1.0f) / (2.0f * PI_F)) * powNoH;
                     const float pdfDir = pdfH / (4.0f * fmaxf(1e-6f, VoH));
                     pdfRefl = pdfDir * (pr / total);
@@ -321,7 +325,7 @@ __device__ __forceinline__ void evaluate_phong_blinn(const PhongCtx& ctx, bool p
         else if (hasSpec || hasRefl) lobe = LOBE_SPECULAR;
         else lobe = LOBE_DIFFUSE;
     } else {
-        const float pr = (max3c(ctx.kr) > 0.0f) ? luma1(ctx.kr + ctx.fresnelRef) : 0.0f;
+        const float pr = ctx.krPos ? luma1(ctx.krf) : 0.0f;
         const float total = pd + ps + pr + pt;
         if (total <= 0.0f) return;
         if (pt > 0.0f) {
@@ -530,20 +534,17 @@ __device__ __forceinline__ bool mtl_is_photon_surface(const DevMaterial& m) {
 }
 
 // ---- PointLight -------------------------------------------------------------------------------------------
-// Shading.cpp:118-165
-__device__ __forceinline__ bool light_generate_sample(const DevLight& L, f3 P, float u1, float u2, f3& dir, DirInfo& si) {
-    set_void(si);
-    const f3 position = ld3(L.pos), intensity = ld3(L.intensity);
+// Shading.cpp:118-165, in two parts so that the NEE kernel (kernels_nee.hip) can keep the direction of a sample and form its
+// weights later: light_sample_dir = the sampled point (direction, distance; false: no sample), light_sample_terms = mult and
+// prob of a sample at that distance. light_generate_sample is the two together, in the reference's order of operations.
+__device__ __forceinline__ bool light_sample_dir(const DevLight& L, f3 P, float u1, float u2, f3& dir, float& distOut) {
+    const f3 position = ld3(L.pos);
     const f3 toC = position - P;
     const float dc = len3(toC);
     if (dc < 1e-6f) return false;
     if (L.size <= 0.0f) {
         dir = toC / dc;
-        const float att_factor = (L.attenuation == 0.0f) ? 1.0f : L.attenuation * L.attenuation;
-        si.mult = intensity / (att_factor * dc * dc);
-        si.prob = 1.0f;
-        si.dist = dc;
-        si.lobe = LOBE_ALL;
+        distOut = dc;
         return true;
     }
     const float z = 1.0f - 2.0f * u1;
@@ -557,14 +558,30 @@ __device__ __forceinline__ bool light_generate_sample(const DevLight& L, f3 P, f
     dir = wi / dist;
     const float cosLight = fmaxf(0.0f, dot3(-onS, dir));
     if (cosLight <= 0.0f) return false;
-    const float area = 4.0f * PI_F * L.size * L.size;
-    const float pdfArea = 2.0f / area;
-    const f3 radiance = intensity / (PI_F * L.size * L.size);
+    distOut = dist;
+    return true;
+}
+__device__ __forceinline__ void light_sample_terms(const DevLight& L, float dist, DirInfo& si) {
+    const f3 intensity = ld3(L.intensity);
     const float att_factor = (L.attenuation == 0.0f) ? 1.0f : L.attenuation * L.attenuation;
-    si.mult = radiance / att_factor;
-    si.prob = pdfArea;
+    if (L.size <= 0.0f) {
+        si.mult = intensity / (att_factor * dist * dist);
+        si.prob = 1.0f;
+    } else {
+        const float area = 4.0f * PI_F * L.size * L.size;
+        const float pdfArea = 2.0f / area;
+        const f3 radiance = intensity / (PI_F * L.size * L.size);
+        si.mult = radiance / att_factor;
+        si.prob = pdfArea;
+    }
     si.dist = dist;
     si.lobe = LOBE_ALL;
+}
+__device__ __forceinline__ bool light_generate_sample(const DevLight& L, f3 P, float u1, float u2, f3& dir, DirInfo& si) {
+    set_void(si);
+    float dist;
+    if (!light_sample_dir(L, P, u1, u2, dir, dist)) return false;
+    light_sample_terms(L, dist, si);
     return si.prob > 0.0f;
 }
 

@@ -34,7 +34,7 @@ void launch_extend(const DevScene& sc, const LaunchCfg& cfg, const float4* rays,
 void launch_extend_queue(const DevScene& sc, const LaunchCfg& cfg, const float4* rays, const SegQ& q, const uint32_t* items,
                          uint32_t n, int hitSide, int withLights, float4* hits);
 void launch_segq_scan2(const SegQ& qa, uint32_t Ga, uint32_t multA, const SegQ& qb, uint32_t Gb, uint32_t multB, uint32_t blockThreads,
-                       uint32_t* totals, hipStream_t stream, unsigned long long* acc = nullptr);
+                       uint32_t* totals, hipStream_t stream);
 // CameraAdapter.h:7-27 pixel-centre rays for the whole image
 void launch_primary_raygen(const DevCamera& cam, float4* rays, hipStream_t stream);
 // compact hit -> full rtx_hit (device array)
@@ -59,13 +59,10 @@ uint32_t launch_raygen(const DevCamera& cam, const PathPool& pool, const int* pi
 uint32_t launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm, const SegQ& qIn,
                       const uint32_t* queueIn, uint32_t n, int bounce, int maxBounces, unsigned long long seed, int sBase, int S,
                       const int* pixels, const SegQ& qOut, uint32_t* queueOut, const SegQ& qShadow, int materialKinds,
-                      hipStream_t stream, uint32_t* keysOut = nullptr);   // materialKinds: bit 0 MtlMicrofacet, bit 1 MtlPhong present
-// ray regrouping (kernels_sort.hip): path slots of queue (qIn, items) in the order of the keys shade wrote -> pool.sortItems
-size_t sort_temp_bytes(uint32_t n);
-int launch_sort_shade_queue(const DevScene& sc, const PathPool& pool, const SegQ& qIn, const uint32_t* items, uint32_t n, void* temp,
-                            size_t tempBytes, hipStream_t stream);
-int launch_sort_queue(const PathPool& pool, const SegQ& qIn, const uint32_t* items, uint32_t n, void* temp, size_t tempBytes,
-                      hipStream_t stream);
+                      hipStream_t stream);   // materialKinds: bit 0 MtlMicrofacet, bit 1 MtlPhong present
+// the (vertex, light) pairs that shade launch (n vertices) has queued in pool.qN, one lane per pair: lobe evaluation, MIS
+// weight, shadow segments appended to qShadow (kernels_nee.hip). The queue must have been scanned; returns the grid size.
+uint32_t launch_nee(const DevScene& sc, const PathPool& pool, uint32_t n, const SegQ& qShadow, int materialKinds, hipStream_t stream);
 // the rest of a pass for its last n paths in one kernel (n <= RTX_TAIL_MAX_PATHS)
 #ifndef RTX_TAIL_MAX_PATHS
 #define RTX_TAIL_MAX_PATHS 65536u

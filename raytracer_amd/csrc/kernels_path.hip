@@ -114,27 +114,6 @@ __global__ void raygen_kernel(DevCamera cam, PathPool pool, const int* __restric
     if (valid) queueOut[q] = slot;
 }
 
-// 5 bits -> every third bit
-__device__ __forceinline__ uint32_t spread5(uint32_t v) {
-    v &= 31u;
-    v = (v | (v << 8)) & 0x100Fu;
-    v = (v | (v << 4)) & 0x10C3u;
-    v = (v | (v << 2)) & 0x1249u;
-    return v;
-}
-__device__ __forceinline__ uint32_t ray_sort_key(const DevScene& sc, const float4 ra, const float4 rb) {
-    uint32_t c[3];
-    const float o[3] = {ra.x, ra.y, ra.z};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float ext = sc.bounds[a + 3] - sc.bounds[a];
-        const float f = ext > 0.0f ? (o[a] - sc.bounds[a]) / ext * 32.0f : 0.0f;
-        c[a] = (uint32_t)fminf(fmaxf(f, 0.0f), 31.0f);
-    }
-    const uint32_t oct = (rb.x < 0.0f ? 1u : 0u) | (rb.y < 0.0f ? 2u : 0u) | (rb.z < 0.0f ? 4u : 0u);
-    return (oct << 15) | spread5(c[0]) | (spread5(c[1]) << 1) | (spread5(c[2]) << 2);
-}
-
 // ---- shade (per-vertex body: shade_body.h) -----------------------------------------------------------------------
 #ifndef SHADE_WAVES_PER_EU
 #define SHADE_WAVES_PER_EU 3
@@ -146,7 +125,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
                                                     SegQ qIn, const uint32_t* __restrict__ queueIn, uint32_t n, int bounce,
                                                     int maxBounces, unsigned long long seed, int sBase, int S,
                                                     const int* __restrict__ pixels, SegQ qOut, uint32_t* __restrict__ queueOut,
-                                                    SegQ qShadow, uint32_t* __restrict__ keysOut) {
+                                                    SegQ qShadow, SegQ qNee) {
     __shared__ uint32_t qtab[SEGQ_TABLE_WORDS];
     segq_load_table(qIn, qtab);
     __syncthreads();
@@ -170,19 +149,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
                 culled = true;
             }
         }
+        // the lobe evaluation of the vertex's light samples is nee_kernel's (kernels_nee.hip): the body queues the pairs in qNee
+        // and leaves the vertex's record at index i of pool.neeCtx
         if (!culled)
-            alive = shade_body<MICRO, false, PHOT, PHONG>(sc, cam, pool, pm, slot, ray, HitT{hv.x, hv.y, hv.z, hitSlot}, bounce, maxBounces, seed,
-                                                          sBase, S, pixels, qShadow);
+            alive = shade_body<MICRO, false, PHOT, PHONG, true>(sc, cam, pool, pm, slot, ray, HitT{hv.x, hv.y, hv.z, hitSlot}, bounce, maxBounces,
+                                                                seed, sBase, S, pixels, qShadow, i, &qNee);
     }
     // ---- surviving paths -> next queue ----
     const uint32_t q = segq_append(qOut, alive, 1u);
-    if (alive) {
-        queueOut[q] = slot;
-        if (keysOut) {   // regrouping key of the path's next ray (kernels_sort.hip): origin cell in Morton order, direction octant
-            const float4 ra = pool.rays[2 * (size_t)slot], rb = pool.rays[2 * (size_t)slot + 1];
-            keysOut[q] = ray_sort_key(sc, ra, rb);
-        }
-    }
+    if (alive) queueOut[q] = slot;
 }
 
 // ---- shadow --------------------------------------------------------------------------------------------------
@@ -554,12 +529,12 @@ uint32_t launch_raygen(const DevCamera& cam, const PathPool& pool, const int* pi
 uint32_t launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm, const SegQ& qIn,
                       const uint32_t* queueIn, uint32_t n, int bounce, int maxBounces, unsigned long long seed, int sBase, int S,
                       const int* pixels, const SegQ& qOut, uint32_t* queueOut, const SegQ& qShadow, int materialKinds,
-                      hipStream_t stream, uint32_t* keysOut) {
+                      hipStream_t stream) {
     if (!n) return 0;
     const uint32_t grid = (n + 255) / 256;
 #define RTX_LAUNCH_SHADE(M, P, G)                                                                                                    \
     hipLaunchKernelGGL((shade_kernel<M, P, G>), dim3(grid), dim3(256), 0, stream, sc, cam, pool, pm, qIn, queueIn, n, bounce, maxBounces, \
-                       seed, sBase, S, pixels, qOut, queueOut, qShadow, keysOut)
+                       seed, sBase, S, pixels, qOut, queueOut, qShadow, pool.qN)
     // materialKinds: bit 0 = the scene holds MtlMicrofacet, bit 1 = MtlPhong; a caustics map selects the gather
     switch ((materialKinds & 3) | (pm.n > 0 ? 4 : 0)) {
         case 0: RTX_LAUNCH_SHADE(false, false, false); break;

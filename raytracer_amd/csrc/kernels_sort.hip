@@ -1,78 +1,11 @@
-// Regrouping of queued bounce rays ACROSS waves before the extend kernel (experiment behind RTX_AMD_SORT, see
-// rtx_render.cpp): rays are keyed by the cell of their origin (32^3 grid over the scene box, Morton order) and the octant
-// of their direction, and the extend launch reads them in key order, so that the 64 rays of a wave walk neighbouring
-// parts of the tree. The keys are written by shade_kernel next to the queue entries; here the segmented queue is
-// gathered into dense arrays and sorted (rocPRIM radix sort over the 18 key bits).
+// Radix-sort passes of the photon map build (rocPRIM): storage order of a map and its capacity rule. (The ray and shade
+// regrouping experiments of round 2 that shared this file - measured negatives, DESIGN.md section 3 - left the tree in
+// round 3; `git log -- raytracer_amd/csrc/kernels_sort.hip` has them.)
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include "kernels.h"
 #include "pathstate.h"
 #include "photon_cell.h"
-
-__global__ void sort_gather_kernel(SegQ qIn, const uint32_t* __restrict__ items, const uint32_t* __restrict__ keys, uint32_t n,
-                                   uint32_t* __restrict__ itemsDense, uint32_t* __restrict__ keysDense) {
-    __shared__ uint32_t qtab[SEGQ_TABLE_WORDS];
-    segq_load_table(qIn, qtab);
-    __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t idx = segq_item_index(qtab, i);
-    itemsDense[i] = items[idx];
-    keysDense[i] = keys[idx];
-}
-
-// Shade-side regrouping (experiment behind RTX_AMD_SORT_SHADE): key = what the vertex will run in shade_kernel - miss,
-// light hit, or the material of the surface hit - so that a wave shades one kind of vertex. The sort is stable, so
-// inside a class the path slots keep their ascending order (the SoA path state is read as coherently as before).
-__global__ void shade_class_gather_kernel(DevScene sc, SegQ qIn, const uint32_t* __restrict__ items, const float4* __restrict__ hits,
-                                          uint32_t n, uint32_t* __restrict__ itemsDense, uint32_t* __restrict__ keysDense) {
-    __shared__ uint32_t qtab[SEGQ_TABLE_WORDS];
-    segq_load_table(qIn, qtab);
-    __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t slot = items[segq_item_index(qtab, i)];
-    const int h = __float_as_int(hits[slot].w);
-    uint32_t key = 0u;                       // miss
-    if (h <= -2) key = 1u;                   // light
-    else if (h >= 0) {
-        const uint32_t obj = sc.attrs[h].obj_mtl & 0xFFFFu;
-        const int mi = sc.objs[obj].material;
-        key = 2u + (uint32_t)(mi < 0 ? 0 : (mi & 61));
-    }
-    itemsDense[i] = slot;
-    keysDense[i] = key;
-}
-int launch_sort_shade_queue(const DevScene& sc, const PathPool& pool, const SegQ& qIn, const uint32_t* items, uint32_t n, void* temp,
-                            size_t tempBytes, hipStream_t stream) {
-    if (!n) return 0;
-    hipLaunchKernelGGL(shade_class_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sc, qIn, items, pool.hits, n, pool.sortItemsIn,
-                       pool.sortKeysIn);
-    size_t bytes = tempBytes;
-    const hipError_t e = rocprim::radix_sort_pairs(temp, bytes, (const uint32_t*)pool.sortKeysIn, pool.sortKeysOut,
-                                                   (const uint32_t*)pool.sortItemsIn, pool.sortItems, (size_t)n, 0u, 6u, stream);
-    return e == hipSuccess ? 0 : -1;
-}
-
-size_t sort_temp_bytes(uint32_t n) {
-    size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                    (size_t)n, 0u, (unsigned)RTX_SORT_KEY_BITS, (hipStream_t) nullptr);
-    return bytes;
-}
-
-// sortedItems[0 .. n) = the queue's path slots in key order
-int launch_sort_queue(const PathPool& pool, const SegQ& qIn, const uint32_t* items, uint32_t n, void* temp, size_t tempBytes,
-                      hipStream_t stream) {
-    if (!n) return 0;
-    hipLaunchKernelGGL(sort_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, qIn, items, pool.sortKeys, n, pool.sortItemsIn,
-                       pool.sortKeysIn);
-    size_t bytes = tempBytes;
-    const hipError_t e = rocprim::radix_sort_pairs(temp, bytes, (const uint32_t*)pool.sortKeysIn, pool.sortKeysOut,
-                                                   (const uint32_t*)pool.sortItemsIn, pool.sortItems, (size_t)n, 0u,
-                                                   (unsigned)RTX_SORT_KEY_BITS, stream);
-    return e == hipSuccess ? 0 : -1;
-}
 
 // ---- photon map order ------------------------------------------------------------------------------------------
 // The photons of a map are stored cell by cell and, inside a cell, by their (photon, bounce) key: the emit kernel

@@ -8,9 +8,11 @@
 // ---- segmented queue control (segqueue.h) ---------------------------------------------------------------------
 // One wave per queue: lane s owns segment s.
 __global__ void segq_scan_kernel(SegQ qa, uint32_t Ga, uint32_t Ba, uint32_t multA, SegQ qb, uint32_t Gb, uint32_t Bb, uint32_t multB,
-                                 uint32_t* totals, uint32_t slotA, uint32_t slotB, unsigned long long* acc) {
+                                 uint32_t* totals, uint32_t slotA, uint32_t slotB, const uint32_t* blocksFrom) {
     const SegQ q = blockIdx.x == 0 ? qa : qb;
-    const uint32_t G = blockIdx.x == 0 ? Ga : Gb, B = blockIdx.x == 0 ? Ba : Bb, mult = blockIdx.x == 0 ? multA : multB;
+    uint32_t G = blockIdx.x == 0 ? Ga : Gb;
+    const uint32_t B = blockIdx.x == 0 ? Ba : Bb, mult = blockIdx.x == 0 ? multA : multB;
+    if (blocksFrom) G = max(1u, (*blocksFrom + B - 1u) / B);
     const uint32_t l = threadIdx.x;
     const uint32_t c = q.ctl[SEGQ_COUNT + l * QSTRIDE];
     uint32_t x = c;   // inclusive scan over the 64 segments
@@ -22,7 +24,6 @@ __global__ void segq_scan_kernel(SegQ qa, uint32_t Ga, uint32_t Ba, uint32_t mul
     if (l == 63u) {
         q.ctl[SEGQ_PREFIX + QSEG] = x;
         totals[blockIdx.x == 0 ? slotA : slotB] = x;
-        if (acc) acc[blockIdx.x] += x;   // one scan at a time per stream: running sums of the entries produced (rtx_render.cpp)
     }
     q.ctl[SEGQ_START + l] = segq_first_block(l, G) * B * mult;
     q.ctl[SEGQ_COUNT + l * QSTRIDE] = 0u;
@@ -38,14 +39,14 @@ __global__ void segq_identity_kernel(SegQ q, uint32_t n) {
     q.ctl[SEGQ_CURSOR + l * QSTRIDE] = 0u;
 }
 void launch_segq_scan(const SegQ& q, uint32_t producerBlocks, uint32_t blockThreads, uint32_t mult, uint32_t* totals,
-                      uint32_t totalsSlot, hipStream_t stream) {
+                      uint32_t totalsSlot, hipStream_t stream, const uint32_t* blocksFrom) {
     hipLaunchKernelGGL(segq_scan_kernel, dim3(1), dim3(64), 0, stream, q, producerBlocks ? producerBlocks : 1u, blockThreads, mult, q, 1u,
-                       blockThreads, mult, totals, totalsSlot, totalsSlot, (unsigned long long*)nullptr);
+                       blockThreads, mult, totals, totalsSlot, totalsSlot, blocksFrom);
 }
 void launch_segq_scan2(const SegQ& qa, uint32_t Ga, uint32_t multA, const SegQ& qb, uint32_t Gb, uint32_t multB, uint32_t blockThreads,
-                       uint32_t* totals, hipStream_t stream, unsigned long long* acc) {
+                       uint32_t* totals, hipStream_t stream) {
     hipLaunchKernelGGL(segq_scan_kernel, dim3(2), dim3(64), 0, stream, qa, Ga ? Ga : 1u, blockThreads, multA, qb, Gb ? Gb : 1u, blockThreads,
-                       multB, totals, 0u, 1u, acc);
+                       multB, totals, 0u, 1u, (const uint32_t*)nullptr);
 }
 void launch_segq_identity(const SegQ& q, uint32_t n, hipStream_t stream) {
     hipLaunchKernelGGL(segq_identity_kernel, dim3(1), dim3(64), 0, stream, q, n);

@@ -12,7 +12,6 @@
 #define PF_LAST_DELTA 1u
 #define PF_INSIDE_MEDIUM 2u
 #define PF_HAS_PREV 4u
-#define RTX_SORT_KEY_BITS 18   // 3 octant bits above 15 Morton bits of a 32^3 origin cell
 
 struct DevPhotonMap {
     const float4* pos;      // xyz, w = photon key    (sorted by cell, then key)
@@ -49,13 +48,10 @@ struct PathPool {
     uint32_t* queueA;
     uint32_t* queueB;
     float4* shadowQ;        // 2 per entry: {offset origin xyz, maxDist}, {unit dir xyz, bits(slot*8+light)}
-    SegQ qA, qB, qS;        // control words of queueA / queueB / shadowQ
-    // ray regrouping before extend (kernels_sort.hip; allocated only when it is switched on)
-    uint32_t* sortKeys;     // key of the ray of every queue entry, written by shade_kernel next to the entry (same index)
-    uint32_t* sortKeysIn;   // dense copies for the radix sort
-    uint32_t* sortKeysOut;
-    uint32_t* sortItemsIn;
-    uint32_t* sortItems;    // path slots in key order: the item list of the next extend launch
+    float4* neeQ;           // 2 per entry: {direction to the sampled point on the light, its distance}, {bits(vertex index of the bounce), bits(light)}
+    SegQ qA, qB, qS, qN;    // control words of queueA / queueB / shadowQ / neeQ
+    size_t neeStride;       // vertices the record array is laid out for (word k of vertex i at neeCtx[k * neeStride + i])
+    float4* neeCtx;         // NEE_CTX_VEC per vertex of the current bounce, indexed by queue position (nee_ctx.h): shade_kernel -> nee_kernel
     uint32_t* totals;       // [0] entries of the queue shade appended to, [1] entries of the shadow queue,
                             // [4] entries of cullPaths, [5] entries of cullShadows
     // Box culls of the reference in scenes of world-space triangles (traverse.h ref_box_hit): the lean

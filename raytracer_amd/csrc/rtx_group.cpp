@@ -4,6 +4,7 @@
 #include "rtx_internal.h"
 #include "photon.h"
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -58,6 +59,10 @@ struct rtx_group {
     size_t filmPixels = 0;
     size_t statPixels = 0;
     int* listDev = nullptr;    // on member 0's device: the pixel list of one member (statPixels entries)
+    // RayCaster::Stop() for the whole group: set by rtx_group_cancel, cleared when rtx_group_render starts. The members' own
+    // flags (rtx_cancel) stop the pass in flight; they are cleared again by every rtx_render_round, so the loop over adaptive
+    // rounds needs a flag of its own that outlives a round.
+    std::atomic<int> cancel{0};
 };
 
 static void free_stats(rtx_pixel_stats& p) {
@@ -161,17 +166,18 @@ static int ensure_films(rtx_group* g, size_t n) {
     (void)hipGetDevice(&prev);
     int rc = RTX_OK;
     for (size_t i = 0; i < g->m.size() && rc == RTX_OK; ++i) {
-        RTX_HIP(hipSetDevice(g->m[i].device));
-        rc = FilmAlloc::create(g->m[i].film, n);
+        if (hipSetDevice(g->m[i].device) != hipSuccess) rc = rtx_fail(RTX_ERR_HIP, "hipSetDevice failed for group member " + std::to_string(i));
+        if (rc == RTX_OK) rc = FilmAlloc::create(g->m[i].film, n);
         if (rc == RTX_OK && i > 0 && g->m[i].device != g->m[0].device) {
-            RTX_HIP(hipSetDevice(g->m[0].device));
-            rc = FilmAlloc::create(g->m[i].staged, n);
+            if (hipSetDevice(g->m[0].device) != hipSuccess) rc = rtx_fail(RTX_ERR_HIP, "hipSetDevice failed for group member 0");
+            if (rc == RTX_OK) rc = FilmAlloc::create(g->m[i].staged, n);
         }
     }
-    (void)hipSetDevice(prev);
+    (void)hipSetDevice(prev);   // the caller's device comes back and the films created so far are released on every way out
     if (rc != RTX_OK) {
+        const std::string msg = rtx_last_error();
         release_films(g);
-        return rc;
+        return rtx_fail(rc, msg);
     }
     g->filmPixels = n;
     return RTX_OK;
@@ -186,6 +192,13 @@ static void add_stats(rtx_stats& a, const rtx_stats& s) {
     a.tris_tested += s.tris_tested;
     a.extend_launches += s.extend_launches;
     a.rays_extend += s.rays_extend;
+    a.shade_launches += s.shade_launches;
+    a.vertices += s.vertices;
+    a.shadow_launches += s.shadow_launches;
+    a.shadow_segments += s.shadow_segments;
+    a.shadow_nodes += s.shadow_nodes;
+    a.shadow_tris += s.shadow_tris;
+    a.nee_ms += s.nee_ms;
     a.extend_ms += s.extend_ms;
     a.shadow_ms += s.shadow_ms;
     a.shade_ms += s.shade_ms;
@@ -247,6 +260,9 @@ static int group_render_adaptive(rtx_group* g, const rtx_camera* cam, const rtx_
     std::vector<int> refine(np), weight, owner;
     int base = 0;
     for (int round = 0;; ++round) {
+        // Stop(): no further round is dealt; the films hold the rounds that completed (a round cancelled in flight drops its
+        // unfinished pass, as rtx_render_accumulate does) and are merged as they are
+        if (g->cancel.load(std::memory_order_relaxed)) break;
         const int nS = std::min(params->spp_min, params->spp_max - base);
         if (nS <= 0) break;
         const bool more = params->spp_max > params->spp_min && base + nS < params->spp_max;
@@ -254,7 +270,7 @@ static int group_render_adaptive(rtx_group* g, const rtx_camera* cam, const rtx_
             Member& mb = g->m[i];
             rtx_stats one;
             std::memset(&one, 0, sizeof(one));
-            if (!mine[i].empty()) {
+            if (!mine[i].empty() && !g->cancel.load(std::memory_order_relaxed)) {   // (a Stop() that came before this member's round began)
                 const int r = rtx_render_round(mb.scene, cam, params, (params->use_photons ? mb.photons : nullptr), &mb.film, &mb.pstats,
                                                mine[i].data(), mine[i].size(), base, nS, round == 1 ? 1 : 0, &one);
                 if (r != RTX_OK) return r;
@@ -269,6 +285,7 @@ static int group_render_adaptive(rtx_group* g, const rtx_camera* cam, const rtx_
             return (int)RTX_OK;
         });
         if (rc != RTX_OK) return rc;
+        if (g->cancel.load(std::memory_order_relaxed)) break;   // the round just dealt was interrupted: its statistics are not to be trusted, nothing is dealt from them
         base += nS;
         if (!more) break;
         // ---- on member 0's device: collect, test, deal ----
@@ -377,6 +394,7 @@ rtx_photons* rtx_group_photons(rtx_group* g, int member) { return (g && member >
 
 int rtx_group_cancel(rtx_group* g) {
     if (!g) return rtx_fail(RTX_ERR_INVALID, "group is NULL");
+    g->cancel.store(1);
     for (Member& mb : g->m) (void)rtx_cancel(mb.scene);
     return RTX_OK;
 }
@@ -387,6 +405,7 @@ int rtx_group_render(rtx_group* g, const rtx_camera* cam, const rtx_render_param
     if (cam->width <= 0 || cam->height <= 0) return rtx_fail(RTX_ERR_INVALID, "invalid camera");
     const int n = (int)g->m.size();
     const size_t np = (size_t)cam->width * cam->height;
+    g->cancel.store(0);
     int rc = ensure_films(g, np);
     if (rc != RTX_OK) return rc;
     const auto t0 = std::chrono::steady_clock::now();
@@ -399,7 +418,7 @@ int rtx_group_render(rtx_group* g, const rtx_camera* cam, const rtx_render_param
         rp.rank = i;
         rp.world = n;
         int r = rtx_film_clear(&mb.film, cam->width, cam->height, nullptr);
-        if (r == RTX_OK) r = rtx_render_accumulate(mb.scene, cam, &rp, (params->use_photons ? mb.photons : nullptr), &mb.film, &st[i]);
+        if (r == RTX_OK && !g->cancel.load(std::memory_order_relaxed)) r = rtx_render_accumulate(mb.scene, cam, &rp, (params->use_photons ? mb.photons : nullptr), &mb.film, &st[i]);
         if (r != RTX_OK) return r;
         // this member's film onto member 0's device: every peer sends over its own xGMI link at the same time
         if (i > 0 && mb.device != g->m[0].device)
@@ -433,6 +452,13 @@ int rtx_group_render(rtx_group* g, const rtx_camera* cam, const rtx_render_param
             a.tris_tested += s.tris_tested;
             a.extend_launches += s.extend_launches;
             a.rays_extend += s.rays_extend;
+            a.shade_launches += s.shade_launches;
+            a.vertices += s.vertices;
+            a.shadow_launches += s.shadow_launches;
+            a.shadow_segments += s.shadow_segments;
+            a.shadow_nodes += s.shadow_nodes;
+            a.shadow_tris += s.shadow_tris;
+            a.nee_ms = std::max(a.nee_ms, s.nee_ms);
             a.extend_ms = std::max(a.extend_ms, s.extend_ms);
             a.shadow_ms = std::max(a.shadow_ms, s.shadow_ms);
             a.shade_ms = std::max(a.shade_ms, s.shade_ms);

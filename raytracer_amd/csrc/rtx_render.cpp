@@ -23,8 +23,6 @@ struct PathPoolHost {
     // second stream: the shadow kernel of bounce k runs beside the extend kernel of bounce k+1
     hipStream_t sideStream = nullptr;
     hipEvent_t sideDone = nullptr;
-    hipEvent_t mainMark = nullptr;   // recorded on the main stream after a bounce's scan when the host does not synchronise there
-    void* sortTemp = nullptr;     // in allocs
     hipEvent_t evTotal0 = nullptr, evTotal1 = nullptr;   // whole-call timing; owned here so that no error path leaks them
     uint2* sideSpill = nullptr;   // its own traversal spill slab (both kernels are in flight at once)
     char* legacyState = nullptr;  // in allocs: legacy_kernel's calls and frames (legacy shading mode only)
@@ -35,16 +33,11 @@ struct PathPoolHost {
     int baseKey[5] = {0, 0, 0, 0, 0};
     uint32_t baseN = 0;
     size_t baseValid = 0;
-    size_t sortTempBytes = 0;
     void release() {
         if (sideStream) {
             (void)hipStreamSynchronize(sideStream);
             (void)hipStreamDestroy(sideStream);
             sideStream = nullptr;
-        }
-        if (mainMark) {
-            (void)hipEventDestroy(mainMark);
-            mainMark = nullptr;
         }
         if (sideDone) {
             (void)hipEventDestroy(sideDone);
@@ -122,9 +115,13 @@ static int ensure_pool(rtx_scene* s, uint32_t slots, size_t framePixels, size_t 
     PA(queueA, qcap);
     PA(queueB, qcap);
     PA(shadowQ, 2 * (size_t)nL * qcap);
+    PA(neeCtx, 8 * qcap);   // NEE_CTX_VEC float4 per vertex of a bounce (nee_ctx.h)
+    d.neeStride = qcap;
     PA(qA.ctl, SEGQ_WORDS);
     PA(qB.ctl, SEGQ_WORDS);
     PA(qS.ctl, SEGQ_WORDS);
+    PA(qN.ctl, SEGQ_WORDS);
+    PA(neeQ, 2 * (size_t)nL * qcap);
     PA(totals, 16);
     PA(cullPaths, RTX_CULL_CAP);
     PA(cullShadows, RTX_CULL_CAP);
@@ -136,17 +133,6 @@ static int ensure_pool(rtx_scene* s, uint32_t slots, size_t framePixels, size_t 
     PA(statSum, ph->framePixels);
     PA(statSum2, ph->framePixels);
     PA(rayCounters, 8);
-    const char* eSort = std::getenv("RTX_AMD_SORT");
-    const char* eSortShade = std::getenv("RTX_AMD_SORT_SHADE");
-    if ((eSort && std::atoi(eSort) != 0) || (eSortShade && std::atoi(eSortShade) != 0)) {
-        PA(sortKeys, qcap);
-        PA(sortKeysIn, qcap);
-        PA(sortKeysOut, qcap);
-        PA(sortItemsIn, qcap);
-        PA(sortItems, qcap);
-        ph->sortTempBytes = sort_temp_bytes((uint32_t)qcap);
-        if ((rc = pool_alloc(ph, (char**)&ph->sortTemp, ph->sortTempBytes)) != RTX_OK) return rc;
-    }
 #undef PA
     return RTX_OK;
 }
@@ -194,7 +180,7 @@ struct PassTimers {
     std::vector<uint32_t> items;   // work items of each span (RTX_AMD_TRACE)
     bool trace = std::getenv("RTX_AMD_TRACE") != nullptr;
     uint32_t nextItems = 0;
-    double ms[3] = {0, 0, 0};
+    double ms[4] = {0, 0, 0, 0};   // extend, shadow, shade + tail, nee
     hipEvent_t get() {
         if (used == ph->events.size()) {
             hipEvent_t e;
@@ -220,7 +206,7 @@ struct PassTimers {
             float t = 0.0f;
             if (hipEventElapsedTime(&t, ph->events[s.second.first], ph->events[s.second.second]) == hipSuccess) ms[s.first] += t;
             if (trace) {   // development aid: one line per timed launch
-                static const char* names[3] = {"extend", "shadow", "shade/tail"};
+                static const char* names[4] = {"extend", "shadow", "shade/tail", "nee"};
                 std::fprintf(stderr, "[rtx trace] %-10s %10u items %9.3f ms\n", names[s.first], items[k++], t);
             }
         }
@@ -298,11 +284,11 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     int S = rp->samples_per_pass;
     if (S <= 0) {
         // Size the path pool for the 288 GB of HBM: the deeper bounces of a pass hold few paths (Russian roulette),
-        // so fewer, larger passes amortise that tail. Use up to 40 % of the free memory, at most 96 GB.
+        // so fewer, larger passes amortise that tail. Use up to 60 % of the free memory, at most 170 GB.
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = (size_t)8 << 30;
-        const size_t perSlot = 192 + 48 * (size_t)std::max(1, s->dev.n_lights);
-        const size_t budget = std::min<size_t>((size_t)(0.4 * (double)freeB), (size_t)96 << 30);
+        const size_t perSlot = 192 + 128 + 80 * (size_t)std::max(1, s->dev.n_lights);   // + NEE record, + 32 B per light of NEE queue
+        const size_t budget = std::min<size_t>((size_t)(0.6 * (double)freeB), (size_t)170 << 30);
         const size_t target = std::max<size_t>(budget / perSlot, 1u << 20);
         S = (int)std::max<size_t>(1, std::min<size_t>((size_t)perRound, target / std::max<uint32_t>(nPix, 1)));
         // a pool kept from an earlier call is memory already paid for (and no longer "free"): use all of it
@@ -353,6 +339,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     RTX_HIP(hipMemsetAsync(pool.qA.ctl, 0, SEGQ_WORDS * sizeof(uint32_t), st));
     RTX_HIP(hipMemsetAsync(pool.qB.ctl, 0, SEGQ_WORDS * sizeof(uint32_t), st));
     RTX_HIP(hipMemsetAsync(pool.qS.ctl, 0, SEGQ_WORDS * sizeof(uint32_t), st));
+    RTX_HIP(hipMemsetAsync(pool.qN.ctl, 0, SEGQ_WORDS * sizeof(uint32_t), st));
     const uint32_t shadowMult = (uint32_t)std::max(1, s->dev.n_lights);
     uint32_t tailMax = RTX_TAIL_MAX_PATHS;
     if (const char* e = std::getenv("RTX_AMD_TAIL_PATHS")) tailMax = std::min<uint32_t>(tailMax, (uint32_t)std::atol(e));   // 0 disables
@@ -371,7 +358,6 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     if (overlap && !legacy && !ph->sideStream) {
         RTX_HIP(hipStreamCreateWithFlags(&ph->sideStream, hipStreamNonBlocking));
         RTX_HIP(hipEventCreateWithFlags(&ph->sideDone, hipEventDisableTiming));
-        RTX_HIP(hipEventCreateWithFlags(&ph->mainMark, hipEventDisableTiming));
         if ((rc = pool_alloc(ph, &ph->sideSpill, (size_t)s->cfg.gridBlocks * TRAV_BLOCK * STACK_GLOBAL)) != RTX_OK) {
             rtx_scene_release_pool(s);   // stream, event and every pool allocation; the next call starts from scratch
             return rc;
@@ -381,34 +367,14 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     sideCfg.stream = ph->sideStream;
     sideCfg.spill = ph->sideSpill;
     bool sidePending = false;   // a shadow launch on the side stream that the main stream has not waited for yet
-    bool sortedNext = false;    // the next extend launch reads pool.sortItems (RTX_AMD_SORT)
-    uint32_t sortMin = 1u << 18;
-    const char* eSortRays = std::getenv("RTX_AMD_SORT");
-    const char* eSortShadeRun = std::getenv("RTX_AMD_SORT_SHADE");
-    if (const char* e = std::getenv("RTX_AMD_SORT_MIN")) sortMin = (uint32_t)std::atol(e);
-    const int sortKind = std::getenv("RTX_AMD_SORT_IN_EXTEND") ? 0 : 2;
-    const bool sortRays = pool.sortKeys && eSortRays && std::atoi(eSortRays) != 0;
-    const bool sortShade = pool.sortKeys && eSortShadeRun && std::atoi(eSortShadeRun) != 0;   // where the sort's time is booked (extend or shade)
-
-    // The counts of a bounce (paths alive, shadow segments) come back to the host every syncEvery-th bounce only; in between
-    // the launches are sized by the last known counts, which bound the later ones from above (paths only die), the kernels
-    // take the true counts from the queues' control words, and the totals are summed on the device (pool.rayCounters[2..3]).
-    // Measured slower than a read-back per bounce (C3, 16 spp: 137.1 ms -> 139.3 / 140.8 / 145.2 ms at 2 / 4 / 8): grids sized by
-    // stale bounds run empty blocks and the tail kernel takes over later than it could, which costs more than the round
-    // trips save. Kept behind RTX_AMD_SYNC_EVERY for callers whose host thread is the bottleneck.
-    int syncEvery = 1;
-    if (const char* e = std::getenv("RTX_AMD_SYNC_EVERY")) syncEvery = std::max(1, std::atoi(e));
-    if (s->cfg.counting || sortRays || sortShade) syncEvery = 1;
-    int shadeKinds = (s->hasMicrofacet ? 1 : 0) | (s->hasPhong ? 2 : 0);   // which forms of the shade kernel the scene needs
-    if (const char* e = std::getenv("RTX_AMD_SHADE_KINDS")) shadeKinds |= std::atoi(e) & 3;   // (measurements: a more general form than needed)
-    unsigned long long handedOver = 0;   // paths counted by the device sums but not traced by an extend launch (tail kernel, bounce limit)
+    const int shadeKinds = (s->hasMicrofacet ? 1 : 0) | (s->hasPhong ? 2 : 0);   // which forms of the shade kernel the scene needs
     // Scenes of world-space triangles run the lean kernels, which leave out the reference's root and object box tests
     // (traverse.h ref_box_hit); with `culls` the shade and shadow kernels find the hits those tests would have removed - about
     // 2 in 10^7 samples of the C3 frame - and the general kernels trace them again: the vertex through the tail kernel, the
     // shadow chain through a second, tiny shadow launch. Opt-in (RTX_AMD_BOX_CULLS=1): the checks cost 4 % of the C3 frame
     // (shadow 162 -> 194 ms: an object id and a box to fetch at the end of every blocked hop), the general kernels 20 %.
     bool culls = false;
-    if (const char* e = std::getenv("RTX_AMD_BOX_CULLS")) culls = std::atoi(e) != 0 && !legacy && !s->dev.has_xf && syncEvery == 1 && !s->cfg.counting;
+    if (const char* e = std::getenv("RTX_AMD_BOX_CULLS")) culls = std::atoi(e) != 0 && !legacy && !s->dev.has_xf && !s->cfg.counting;
     if (!culls) pool.cullPaths = pool.cullShadows = nullptr;
     DevScene devGeneral = s->dev;
     if (culls) devGeneral.has_xf = 1;   // tail kernel and re-traces: the instantiation that repeats the box tests
@@ -453,57 +419,36 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 RTX_HIP(hipStreamSynchronize(st));   // one pass at a time, so that rtx_cancel is seen between passes
                 n = 0;
             }
-            bool exact = true;   // n is the true count (else an upper bound)
-            bool limitHit = false;
             for (int bounce = 0; bounce < rp->max_bounces && n > 0 && !s->cancel.load(std::memory_order_relaxed); ++bounce) {
                 if (bounce == 0) out.rays_primary += n;
-                else if (syncEvery == 1) out.rays_bounce += n;
+                else out.rays_bounce += n;
                 tm.nextItems = n;
                 tm.begin(0, st);
-                if (sortedNext) {   // the bounce rays in key order (kernels_sort.hip)
-                    launch_segq_identity(s->cfg.identQ, n, st);
-                    launch_extend_queue(s->dev, s->cfg, pool.rays, s->cfg.identQ, pool.sortItems, n, RTX_HIT_FRONT_AND_BACK, 1, pool.hits);
-                } else
-                    launch_extend_queue(s->dev, s->cfg, pool.rays, sqIn, qin, n, RTX_HIT_FRONT_AND_BACK, 1, pool.hits);
+                launch_extend_queue(s->dev, s->cfg, pool.rays, sqIn, qin, n, RTX_HIT_FRONT_AND_BACK, 1, pool.hits);
                 tm.end(st);
-                sortedNext = false;
                 out.extend_launches++;
                 if (sidePending) {
                     RTX_HIP(hipStreamWaitEvent(st, ph->sideDone, 0));
                     sidePending = false;
                 }
+                // shade: the vertex itself (hit, bump, emission, BSDF sample, next ray); nee: its light samples, one lane per
+                // (vertex, light), which appends the shadow segments (kernels_nee.hip)
                 tm.begin(2, st);
-                const uint32_t* shadeItems = qin;
-                SegQ shadeQ = sqIn;
-                if (sortShade && bounce >= 1 && n >= sortMin) {   // vertices regrouped by what they will run (kernels_sort.hip)
-                    if (launch_sort_shade_queue(s->dev, pool, sqIn, qin, n, ph->sortTemp, ph->sortTempBytes, st) != 0)
-                        return rtx_fail(RTX_ERR_HIP, "shade sort failed");
-                    launch_segq_identity(s->cfg.identQ, n, st);
-                    shadeItems = pool.sortItems;
-                    shadeQ = s->cfg.identQ;
-                }
-                const uint32_t gridShade = launch_shade(s->dev, dc, pool, pm, shadeQ, shadeItems, n, bounce, rp->max_bounces, rp->seed, sBase, Sp,
-                                                        curPixels, sqOut, qout, pool.qS, shadeKinds, st, sortRays ? pool.sortKeys : nullptr);
+                const uint32_t gridShade = launch_shade(s->dev, dc, pool, pm, sqIn, qin, n, bounce, rp->max_bounces, rp->seed, sBase, Sp,
+                                                        curPixels, sqOut, qout, pool.qS, shadeKinds, st);
                 tm.end(st);
-                launch_segq_scan2(sqOut, gridShade, 1, pool.qS, gridShade, shadowMult, 256, pool.totals, st,
-                                  syncEvery > 1 ? pool.rayCounters + 2 : nullptr);
-                // read the counts back now? Always at the last bounce, where the paths left over must be known, and while the
-                // launches are large enough not to care; bounds that have come near the tail kernel's regime are checked too
-                const bool lastBounce = bounce + 1 >= rp->max_bounces;
-                const bool syncNow = syncEvery == 1 || lastBounce || n > (8u << 20) || (bounce + 1) % syncEvery == 0;
-                uint32_t cnt[6] = {n, (uint32_t)std::min<unsigned long long>((unsigned long long)n * shadowMult, 0xFFFFFFFFull), 0, 0, 0, 0};   // upper bounds
-                if (syncNow) {
-                    RTX_HIP(hipMemcpyAsync(cnt, pool.totals, sizeof(cnt), hipMemcpyDeviceToHost, st));
-                    RTX_HIP(hipStreamSynchronize(st));
-                }
-                exact = syncNow;
-                // what goes to the side stream must run after shade(k): the host has just synchronised the main stream, or the
-                // side stream waits for a mark recorded behind the scan
+                launch_segq_scan2(sqOut, gridShade, 1, pool.qN, gridShade, shadowMult, 256, pool.totals, st);   // totals[0] paths alive, [1] pairs
+                tm.begin(3, st);
+                const uint32_t gridNee = launch_nee(s->dev, pool, n, pool.qS, shadeKinds, st);
+                tm.end(st);
+                out.shade_launches++;
+                out.vertices += n;
+                // (the shadow queue is laid out by the blocks of the nee grid that held pairs: their number comes from the pair count)
+                launch_segq_scan(pool.qS, gridNee, 256, 1, pool.totals, 1, st, pool.qN.ctl + SEGQ_PREFIX + QSEG);   // totals[1] shadow segments
+                uint32_t cnt[6] = {0, 0, 0, 0, 0, 0};   // paths alive, shadow segments, -, -, culled vertices, culled chains
+                RTX_HIP(hipMemcpyAsync(cnt, pool.totals, sizeof(cnt), hipMemcpyDeviceToHost, st));
+                RTX_HIP(hipStreamSynchronize(st));
                 const bool side = overlap && cnt[1] > 0 && cnt[0] > 0 && cnt[0] <= overlapMax;   // cnt[0] = 0: nothing to overlap with
-                if (side && !syncNow) {
-                    RTX_HIP(hipEventRecord(ph->mainMark, st));
-                    RTX_HIP(hipStreamWaitEvent(ph->sideStream, ph->mainMark, 0));
-                }
                 hipStream_t sst = side ? ph->sideStream : st;
                 if (cnt[1]) {
                     tm.nextItems = cnt[1];
@@ -511,6 +456,8 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                     launch_shadow(s->dev, side ? sideCfg : s->cfg, pool, pool.qS, cnt[1], (bounce <= 8 ? 1 : 0) | shadowFlags);   // useTransmittance (RayCaster.cpp:454)
                     if (culls) launch_shadow_culled(devGeneral, side ? sideCfg : s->cfg, pool, ph->qCull, (bounce <= 8 ? 1 : 0) | shadowFlags);
                     tm.end(sst);
+                    out.shadow_launches++;
+                    out.shadow_segments += cnt[1];
                 }
                 if (side) {
                     RTX_HIP(hipEventRecord(ph->sideDone, ph->sideStream));
@@ -535,18 +482,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 std::swap(qin, qout);
                 std::swap(sqIn, sqOut);
                 n = cnt[0];
-                if (lastBounce && syncEvery > 1) {
-                    handedOver += n;
-                    limitHit = true;
-                }   // alive at the bounce limit: counted by the device sum, never traced
-                if (sortRays && n >= sortMin && n > tailMax && bounce + 1 < rp->max_bounces) {
-                    tm.nextItems = n;
-                    tm.begin(sortKind, st);
-                    if (launch_sort_queue(pool, sqIn, qin, n, ph->sortTemp, ph->sortTempBytes, st) != 0) return rtx_fail(RTX_ERR_HIP, "ray sort failed");
-                    tm.end(st);
-                    sortedNext = true;
-                }
-                if (exact && n > 0 && n <= tailMax && bounce + 1 < rp->max_bounces) {
+                if (n > 0 && n <= tailMax && bounce + 1 < rp->max_bounces) {
                     // few paths left: one kernel walks them to their ends (tail_kernel)
                     if (sidePending) {
                         RTX_HIP(hipStreamWaitEvent(st, ph->sideDone, 0));
@@ -557,7 +493,6 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                     launch_tail(devGeneral, s->cfg, dc, pool, pm, sqIn, qin, n, bounce + 1, rp->max_bounces, rp->seed, sBase, Sp, curPixels,
                                 (s->hasMicrofacet || s->hasPhong) ? 1 : 0, pm.n > 0 ? 1 : 0);
                     tm.end(st);
-                    if (syncEvery > 1) handedOver += n;   // their first rays are the tail kernel's (rayCounters[1])
                     n = 0;
                 }
                 if (tm.spans.size() > 2048) {
@@ -565,14 +500,6 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                     if (ph->sideStream) RTX_HIP(hipStreamSynchronize(ph->sideStream));
                     tm.flush();
                 }
-            }
-            if (syncEvery > 1 && n > 0 && !limitHit) {   // cancelled: the paths alive now were counted on the device but never traced
-                uint32_t left = n;
-                if (!exact) {
-                    RTX_HIP(hipMemcpyAsync(&left, pool.totals, sizeof(left), hipMemcpyDeviceToHost, st));
-                    RTX_HIP(hipStreamSynchronize(st));
-                }
-                handedOver += left;
             }
             if (sidePending) {   // a cancelled pass, or max_bounces reached with paths alive
                 RTX_HIP(hipStreamWaitEvent(st, ph->sideDone, 0));
@@ -609,15 +536,15 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     tm.flush();
     float total = 0.0f;
     (void)hipEventElapsedTime(&total, evTotal0, evTotal1);
-    unsigned long long rc2[4] = {0, 0, 0, 0};   // [0] shadow hops, [1] closest-hit rays traced inside tail_kernel, [2] paths that left a shade launch alive
+    unsigned long long rc2[4] = {0, 0, 0, 0};   // [0] shadow hops, [1] closest-hit rays traced inside tail_kernel
     RTX_HIP(hipMemcpy(rc2, pool.rayCounters, sizeof(rc2), hipMemcpyDeviceToHost));
-    if (syncEvery > 1 && !legacy) out.rays_bounce += rc2[2] - std::min(rc2[2], handedOver);   // every one of them was traced by the next extend launch, but for these
     out.rays_shadow = rc2[0];
     out.rays_extend = out.rays_primary + out.rays_bounce;   // traced by extend launches (the rest: tail / legacy kernel)
     out.rays_bounce += rc2[1];
     out.extend_ms = tm.ms[0];
     out.shadow_ms = tm.ms[1];
-    out.shade_ms = tm.ms[2];
+    out.shade_ms = tm.ms[2] + tm.ms[3];
+    out.nee_ms = tm.ms[3];
     out.total_ms = total;
     if (s->cfg.counting) {
         unsigned long long c[3];

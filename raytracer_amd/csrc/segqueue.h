@@ -35,8 +35,13 @@ __host__ __device__ inline uint32_t segq_first_block(uint32_t s, uint32_t G) {
 #ifdef __HIPCC__
 // Producer side: every lane of the wave calls this (pred = lane has an entry); returns the item index to write.
 // mult = entries a producer thread can append at most (region size per block = blockDim.x * mult).
-__device__ __forceinline__ uint32_t segq_append(const SegQ& q, bool pred, uint32_t mult) {
-    const uint32_t seg = segq_segment_of_block(blockIdx.x, gridDim.x);
+// G: the number of producer blocks the queue's regions are laid out for. It is the grid size, unless the grid is an upper bound
+// whose tail blocks produce nothing (nee_kernel): all entries would then crowd into the first few segments, and the persistent
+// consumers, which start spread over the 64 segments, would queue up behind a handful of cursors.
+__device__ __forceinline__ uint32_t segq_append_g(const SegQ& q, bool pred, uint32_t mult, uint32_t G);
+__device__ __forceinline__ uint32_t segq_append(const SegQ& q, bool pred, uint32_t mult) { return segq_append_g(q, pred, mult, gridDim.x); }
+__device__ __forceinline__ uint32_t segq_append_g(const SegQ& q, bool pred, uint32_t mult, uint32_t G) {
+    const uint32_t seg = segq_segment_of_block(blockIdx.x, G);
     const unsigned long long mask = __ballot(pred);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = (uint32_t)__popcll(mask);
@@ -47,7 +52,20 @@ __device__ __forceinline__ uint32_t segq_append(const SegQ& q, bool pred, uint32
         base = __shfl(base, leader);
     }
     const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    return segq_first_block(seg, gridDim.x) * blockDim.x * mult + base + prefix;
+    return segq_first_block(seg, G) * blockDim.x * mult + base + prefix;
+}
+
+// The same for a wave that appends `total` entries at once (wave-uniform, > 0; every active lane calls): returns the item
+// index of the first; the caller hands out [first, first + total) among its lanes.
+__device__ __forceinline__ uint32_t segq_reserve(const SegQ& q, uint32_t total, uint32_t mult) {
+    const uint32_t seg = segq_segment_of_block(blockIdx.x, gridDim.x);
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long mask = __ballot(true);
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(&q.ctl[SEGQ_COUNT + seg * QSTRIDE], total);
+    base = __shfl(base, leader);
+    return segq_first_block(seg, gridDim.x) * blockDim.x * mult + base;
 }
 
 // Flat consumer: item index of entry i (i < total). tab = LDS copy of prefix[QSEG+1] followed by start[QSEG],
@@ -129,8 +147,10 @@ __device__ __forceinline__ uint32_t segq_take(const SegQ& q, SegWalk& w, uint32_
 // Host-callable wrappers (kernels_trace.hip)
 // counts -> prefix/start/total for a queue produced by a grid of G blocks of B threads appending <= mult entries per
 // thread; zeroes the counters and cursors; totals[slot] = number of entries.
+// blocksFrom (optional): a queue total on the device; the producer grid then counts ceil(*blocksFrom / blockThreads) blocks
+// (a producer launched over an upper bound that lays its regions out by the true count: nee_kernel)
 void launch_segq_scan(const SegQ& q, uint32_t producerBlocks, uint32_t blockThreads, uint32_t mult, uint32_t* totals,
-                      uint32_t totalsSlot, hipStream_t stream);
+                      uint32_t totalsSlot, hipStream_t stream, const uint32_t* blocksFrom = nullptr);
 // identity queue over [0, n): segment s covers [s*n/QSEG, (s+1)*n/QSEG)
 void launch_segq_identity(const SegQ& q, uint32_t n, hipStream_t stream);
 // entries a persistent consumer wave reserves per atomic, for n entries drained by `waves` waves

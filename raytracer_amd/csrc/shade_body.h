@@ -8,6 +8,7 @@
 #include "shadow.h"
 #include "photon_gather.h"
 #include "segqueue.h"
+#include "nee_ctx.h"
 
 // ---- shade ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ f3 apply_absorption(f3 c, f3 absorption, float dist) {   // RayCaster.cpp:281-301
@@ -51,14 +52,17 @@ __device__ __forceinline__ bool has_map_or_value(const float* c, int tex) {   //
 // (RayCaster.cpp:470-522), in the reference's order of additions into L. There is no resolve launch: the additions of
 // bounce k are made by whoever reads the path's L next - the shading of bounce k+1 (they come before that vertex's own
 // terms, as in the reference), the tail kernel, or the film kernel for a path that ended at bounce k.
-// Returns false when nothing is pending (pendBeta.w < 0).
+// Returns false when nothing is pending (pendBeta.w < 0); otherwise pendBeta.w is the set of lights (bit l) whose nee record
+// the vertex has written - the others sampled nothing that could contribute and have no record.
 __device__ __forceinline__ bool resolve_add(const PathPool& pool, uint32_t slot, int nLights, bool usePhotons, f3& L) {
     const float4 pb = pool.pendBeta[slot];
     if (pb.w < 0.0f) return false;
+    const uint32_t lights = (uint32_t)pb.w;
     const f3 beta = mk3(pb.x, pb.y, pb.z);
     f3 direct = mk3(0.0f);
     float maxVisibility = 0.0f;
     for (int l = 0; l < nLights; ++l) {
+        if (((lights >> l) & 1u) == 0u) continue;
         const float4 c = pool.nee[(size_t)l * pool.capacity + slot];
         if (c.w < 0.0f) continue;
         maxVisibility = fmaxf(maxVisibility, c.w);
@@ -94,11 +98,13 @@ __device__ __forceinline__ void resolve_slot(const PathPool& pool, uint32_t slot
 // Glossiness; false: only the Blinn form of the lobes and only the Diffuse / Emission / bump textures are compiled in (the
 // Phong form costs the kernel 26 ms per C3 frame by being there, the four texture fetches 10 ms: every material of
 // cerealBar.xml is MtlBlinn, textured in Diffuse, Emission and bump only).
-template <bool MICRO, bool TAIL, bool PHOT = true, bool PHONG = true>
+// SPLIT: the lobe evaluation of the light loop is left to nee_kernel (kernels_nee.hip): the body samples the lights, appends
+// the (vertex, light) pairs that can contribute to the NEE queue qNee and writes the vertex's record (nee_ctx.h) at neeIndex.
+template <bool MICRO, bool TAIL, bool PHOT = true, bool PHONG = true, bool SPLIT = false>
 __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pmArg,
                                            uint32_t slot, const RayT& ray, const HitT& h, int bounce, int maxBounces,
                                            unsigned long long seed, int sBase, int S, const int* __restrict__ pixels,
-                                           const SegQ& qShadow) {
+                                           const SegQ& qShadow, uint32_t neeIndex = 0u, const SegQ* qNee = nullptr) {
     DevPhotonMap pm = pmArg;
     if (!PHOT) pm.n = 0;   // every `pm.n > 0` below folds to false
     bool alive = false;
@@ -126,6 +132,7 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
         const int pix = pixels[(cs / (uint32_t)S) * 64u + lane64];
         const int sIdx = sBase + (int)(cs % (uint32_t)S);
         bool pending = false;   // NEE of this bounce to be resolved
+        uint32_t pendMask = sc.n_lights >= 32 ? 0xFFFFFFFFu : (1u << sc.n_lights) - 1u;   // lights whose nee records this vertex writes (resolve_add)
 
         do {
             if (h.slot == -1) {
@@ -215,49 +222,106 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
             // ---- next event estimation: contributions now, visibility by the shadow kernel (:456-503) ----
             const bool photonSurface = mtl_is_photon_surface(*mtl);
             const bool wantCaustic = pm.n > 0 && photonSurface;
-            for (int l = 0; l < sc.n_lights; ++l) {
-                const DevLight& light = sc.lights[l];
-                f3 ldir;
-                DirInfo li;
-                float4 contrib = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
-                const float u1 = sx.rnd(DIM_LIGHT0 + 2 * l), u2 = sx.rnd(DIM_LIGHT0 + 2 * l + 1);
-                if (light_generate_sample(light, sx.P, u1, u2, ldir, li) && li.prob > 0.0f && max3c(li.mult) > 0.0f) {
-                    const float shadowMax = (li.dist > 0.0f && li.dist < RTX_BIG * 0.5f) ? li.dist : RTX_BIG;
-                    DirInfo bs;
-                    if (micro) evaluate_microfacet(mctx, sx, safe_normalize3(ldir), bs);
-                    else evaluate_phong_blinn(ctx, phong, sx, safe_normalize3(ldir), bs);
-                    f3 c = mk3(0.0f);
-                    if (bs.prob > 0.0f && max3c(bs.mult) > 0.0f) {
-                        if (light.size > 0.0f) {
-                            const float dist = li.dist;
-                            const float cosLight = light_cos_for_nee(light, sh.p, safe_normalize3(ldir));
-                            const float pdfSolidAngle = (cosLight > 1e-6f && dist > 1e-6f) ? li.prob * dist * dist / cosLight : 0.0f;
-                            if (pdfSolidAngle > 0.0f) {
-                                const float w = power_heuristic(pdfSolidAngle, bs.prob);
-                                const float G = 1.0f / fmaxf(1e-6f, dist * dist);
-                                c = li.mult * bs.mult * G * (w / fmaxf(1e-6f, li.prob));
+            if (SPLIT) {
+                // Stage A of the light loop, for every light at once: the point on the light and the rejections that need no
+                // lobe evaluation (no sample; light behind a surface that lets none through and no caustics map asking for the
+                // visibility: GetSampleInfo returns nothing there, Shading.cpp:639-646, MtlMicrofacet :905). The pairs that are
+                // left - one in four - go to the NEE queue with their direction; nee_kernel evaluates them packed. The vertex's
+                // record is written only if a pair is left, and pendBeta.w names the lights whose nee records exist.
+                const f3 cN = micro ? mctx.N : ctx.N;
+                const bool behindToo = wantCaustic || (micro ? mctx.pt > 0.0f : luma1(ctx.transColor) > 0.0f);
+                uint32_t lightMask = 0u;
+                for (int l0 = 0; l0 < sc.n_lights; l0 += 4) {
+                    f3 ld[4];
+                    float dd[4];
+                    unsigned long long bal[4];
+                    uint32_t waveTotal = 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int l = l0 + k;
+                        bool surv = false;
+                        ld[k] = mk3(0.0f);
+                        dd[k] = 0.0f;
+                        if (l < sc.n_lights) {
+                            const DevLight& light = sc.lights[l];
+                            const float u1 = sx.rnd(DIM_LIGHT0 + 2 * l), u2 = sx.rnd(DIM_LIGHT0 + 2 * l + 1);
+                            if (light_sample_dir(light, sx.P, u1, u2, ld[k], dd[k])) {
+                                DirInfo li;
+                                light_sample_terms(light, dd[k], li);
+                                if (li.prob > 0.0f && max3c(li.mult) > 0.0f)   // (dir is normalised twice on its way into GetSampleInfo: RayCaster.cpp:475, Shading.cpp:535)
+                                    surv = behindToo || dot3(cN, safe_normalize3(safe_normalize3(ld[k]))) > 0.0f;
                             }
-                        } else {
-                            const float w = power_heuristic(li.prob, bs.prob);
-                            c = li.mult * bs.mult * (w / fmaxf(1e-4f, li.prob));
+                        }
+                        if (surv) lightMask |= 1u << l;
+                        bal[k] = __ballot(surv);
+                        waveTotal += (uint32_t)__popcll(bal[k]);
+                    }
+                    if (waveTotal) {   // one atomic per wave for the group's pairs; entries light by light
+                        uint32_t at = segq_reserve(*qNee, waveTotal, (uint32_t)sc.n_lights);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if ((lightMask >> (l0 + k)) & 1u) {
+                                const size_t e = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[k], 0u));
+                                pool.neeQ[2 * e] = make_float4(ld[k].x, ld[k].y, ld[k].z, dd[k]);
+                                pool.neeQ[2 * e + 1] = make_float4(__uint_as_float(neeIndex), __uint_as_float((uint32_t)(l0 + k)), 0.0f, 0.0f);
+                            }
+                            at += (uint32_t)__popcll(bal[k]);
                         }
                     }
-                    // the shadow segment is needed when it can contribute, or when its visibility scales the
-                    // caustic term (:468, :518)
-                    if (max3c(c) > 0.0f || wantCaustic) {
-                        contrib = make_float4(c.x, c.y, c.z, 0.0f);
-                        pending = true;
-                        const f3 so = offset_point(sh.p, sx.GN, ldir);
-                        const f3 sd = safe_normalize3(ldir);
-                        // wave-wide append of the lanes that reach this point (ballot counts active lanes only)
-                        const uint32_t qs = TAIL ? slot * shadowMult + (uint32_t)l : segq_append(qShadow, true, shadowMult);
-                        pool.shadowQ[2 * (size_t)qs] = make_float4(so.x, so.y, so.z, shadowMax);
-                        pool.shadowQ[2 * (size_t)qs + 1] = make_float4(sd.x, sd.y, sd.z, __uint_as_float(slot * 8u + (uint32_t)l));
-                    }
                 }
-                pool.nee[(size_t)l * cap + slot] = contrib;
+                if (lightMask) {
+                    const uint32_t nf = (sx.front ? NEEF_FRONT : 0u) | (phong ? NEEF_PHONG : 0u) | (wantCaustic ? NEEF_CAUSTIC : 0u);
+                    float4* rec = pool.neeCtx + neeIndex;
+                    if (micro) nee_ctx_store_micro(rec, pool.neeStride, slot, nf, sh.p, sx.GN, mctx);
+                    else nee_ctx_store(rec, pool.neeStride, slot, nf, sh.p, sx.GN, ctx);
+                    pending = true;
+                    pendMask = lightMask;
+                }
+            } else {
+                for (int l = 0; l < sc.n_lights; ++l) {
+                    const DevLight& light = sc.lights[l];
+                    f3 ldir;
+                    DirInfo li;
+                    float4 contrib = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+                    const float u1 = sx.rnd(DIM_LIGHT0 + 2 * l), u2 = sx.rnd(DIM_LIGHT0 + 2 * l + 1);
+                    if (light_generate_sample(light, sx.P, u1, u2, ldir, li) && li.prob > 0.0f && max3c(li.mult) > 0.0f) {
+                        const float shadowMax = (li.dist > 0.0f && li.dist < RTX_BIG * 0.5f) ? li.dist : RTX_BIG;
+                        DirInfo bs;
+                        if (micro) evaluate_microfacet(mctx, sx, safe_normalize3(ldir), bs);
+                        else evaluate_phong_blinn(ctx, phong, sx, safe_normalize3(ldir), bs);
+                        f3 c = mk3(0.0f);
+                        if (bs.prob > 0.0f && max3c(bs.mult) > 0.0f) {
+                            if (light.size > 0.0f) {
+                                const float dist = li.dist;
+                                const float cosLight = light_cos_for_nee(light, sh.p, safe_normalize3(ldir));
+                                const float pdfSolidAngle = (cosLight > 1e-6f && dist > 1e-6f) ? li.prob * dist * dist / cosLight : 0.0f;
+                                if (pdfSolidAngle > 0.0f) {
+                                    const float w = power_heuristic(pdfSolidAngle, bs.prob);
+                                    const float G = 1.0f / fmaxf(1e-6f, dist * dist);
+                                    c = li.mult * bs.mult * G * (w / fmaxf(1e-6f, li.prob));
+                                }
+                            } else {
+                                const float w = power_heuristic(li.prob, bs.prob);
+                                c = li.mult * bs.mult * (w / fmaxf(1e-4f, li.prob));
+                            }
+                        }
+                        // the shadow segment is needed when it can contribute, or when its visibility scales the
+                        // caustic term (:468, :518)
+                        if (max3c(c) > 0.0f || wantCaustic) {
+                            contrib = make_float4(c.x, c.y, c.z, 0.0f);
+                            pending = true;
+                            const f3 so = offset_point(sh.p, sx.GN, ldir);
+                            const f3 sd = safe_normalize3(ldir);
+                            // wave-wide append of the lanes that reach this point (ballot counts active lanes only)
+                            const uint32_t qs = TAIL ? slot * shadowMult + (uint32_t)l : segq_append(qShadow, true, shadowMult);
+                            pool.shadowQ[2 * (size_t)qs] = make_float4(so.x, so.y, so.z, shadowMax);
+                            pool.shadowQ[2 * (size_t)qs + 1] = make_float4(sd.x, sd.y, sd.z, __uint_as_float(slot * 8u + (uint32_t)l));
+                        }
+                    }
+                    pool.nee[(size_t)l * cap + slot] = contrib;
+                }
             }
-            if (pending) pool.pendBeta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
+            if (pending) pool.pendBeta[slot] = make_float4(beta.x, beta.y, beta.z, (float)pendMask);
 
             if (pm.n > 0) {   // :508-522 (scaled by the visibility in resolve_add)
                 float4 cz = make_float4(0.0f, 0.0f, 0.0f, 0.0f);

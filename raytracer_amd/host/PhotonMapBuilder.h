@@ -55,6 +55,7 @@ public:
             }
             handle = rtx_group_photons(gs.Group(), 0);
             borrowed = true;
+            borrowedGeneration = GpuSceneGeneration();
         } else if (rtx_photon_build(gs.Handle(), &p, &handle, nullptr) != RTX_OK) {
             std::cerr << "Photon map build failed: " << rtx_last_error() << "\n";   // logged, render continues (:54-59)
             return;
@@ -70,9 +71,11 @@ public:
         std::cout << "Photon map contains " << counts[0] << " photons\nCaustics map contains " << counts[1] << " photons\n";
     }
 
-    PhotonMap const* GetPhotonMap() const { return &photonMap; }
-    PhotonMap const* GetCausticsMap() const { return &causticsMap; }
-    rtx_photons* Handle() const { return handle; }
+    PhotonMap const* GetPhotonMap() const { Validate(); return &photonMap; }
+    PhotonMap const* GetCausticsMap() const { Validate(); return &causticsMap; }
+    // nullptr once the GPU group that owns the maps is gone (ReleaseGpuScenes: a new device list, a new scene): the maps
+    // went with it, and the next BuildPhotonMap makes new ones
+    rtx_photons* Handle() const { Validate(); return handle; }
 
     // PhotonMapBuilder.h:26-39
     void SetNumPhotons(int n) { numPhotons = n; }
@@ -92,14 +95,23 @@ public:
     void SetSeed(uint64_t s) { seed = s; }
 
 private:
+    void Validate() const {
+        if (handle && borrowed && borrowedGeneration != GpuSceneGeneration()) {
+            handle = nullptr;
+            borrowed = false;
+            photonMap.owner = causticsMap.owner = nullptr;
+        }
+    }
     void Release() {
+        Validate();
         if (handle && !borrowed) rtx_photons_destroy(handle);
         handle = nullptr;
         borrowed = false;
     }
-    PhotonMap photonMap, causticsMap;
-    rtx_photons* handle = nullptr;
-    bool borrowed = false;              // the handle belongs to a GPU group (SceneAdapter.h: g_rtDevices)
+    mutable PhotonMap photonMap, causticsMap;
+    mutable rtx_photons* handle = nullptr;
+    mutable bool borrowed = false;      // the handle belongs to a GPU group (SceneAdapter.h: g_rtDevices) ...
+    unsigned long borrowedGeneration = 0;   // ... and is valid while no ReleaseGpuScenes() has run since
     int numPhotons = 10000000;          // PhotonMapBuilder.h:46-54
     float photonSearchRadius = 0.2f;
     float causticSearchRadius = 0.05f;

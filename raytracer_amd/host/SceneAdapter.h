@@ -193,6 +193,15 @@ inline GpuScene& GetGpuScene(const Scene* scene, const Node* root = nullptr) {
     if (it == reg.end()) it = reg.emplace(key, std::make_unique<GpuScene>(*scene, key.second)).first;
     return *it->second;
 }
-inline void ReleaseGpuScenes() { GpuSceneRegistry().clear(); }
+// Counts the calls of ReleaseGpuScenes(): whoever keeps a handle that a GpuScene owns (PhotonMapBuilder keeps the photon maps
+// of a GPU group) compares it with the value it saw when it took the handle.
+inline unsigned long& GpuSceneGeneration() {
+    static unsigned long gen = 0;
+    return gen;
+}
+inline void ReleaseGpuScenes() {
+    ++GpuSceneGeneration();
+    GpuSceneRegistry().clear();
+}
 
 }  // namespace rtamd

@@ -11,6 +11,6 @@ for line in open(sys.argv[2]):
     if line.startswith('{"metric"'):
         j=json.loads(line)
         k=j["kernel_ms_per_frame_rank0"]
-        print(f'{sys.argv[1]:>10}: frame {j["ms_per_step"]:8.1f} ms  {j["value"]:7.1f} Mrays/s  extend {k["extend"]:7.1f} shadow {k["shadow"]:7.1f} shade {k["shade"]:7.1f}  mean {j["mean_linear"]:.6f}')
+        print(f'{sys.argv[1]:>10}: frame {j["ms_per_step"]:8.1f} ms  {j["value"]:7.1f} Mrays/s  extend {k["extend"]:7.1f} shadow {k["shadow"]:7.1f} shade {k["shade"]:7.1f} (nee {k.get("nee",0):6.1f})  mean {j["mean_linear"]:.6f}')
 PY
 done

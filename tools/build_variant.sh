@@ -13,7 +13,7 @@ tmp=$(mktemp -d)
 mkdir -p "$out"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -I$src $*"
 pids=()
-for f in kernels_trace.hip kernels_path.hip kernels_tail.hip kernels_legacy.hip kernels_photon.hip kernels_post.hip kernels_sort.hip rtx_noalloc.hip rtx_api.cpp rtx_render.cpp rtx_photon.cpp rtx_group.cpp bvh_build.cpp; do
+for f in kernels_trace.hip kernels_path.hip kernels_nee.hip kernels_tail.hip kernels_legacy.hip kernels_photon.hip kernels_post.hip kernels_sort.hip rtx_noalloc.hip rtx_api.cpp rtx_render.cpp rtx_photon.cpp rtx_group.cpp bvh_build.cpp; do
   extra=""
   [ "$f" = kernels_path.hip ] && extra="$PATH_DIV $PATH_FLAGS"
   /opt/rocm/bin/hipcc $FLAGS $extra -c "$src/$f" -o "$tmp/${f%.*}.o" &
