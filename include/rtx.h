@@ -470,7 +470,8 @@ int rtx_get_counters(rtx_scene* scene, uint64_t out[3]);
  * item index of segment s (64 segments), segment_of_block[b] for every block (array of producer_blocks). */
 int rtx_debug_validate_bvh(const rtx_scene_desc* desc, uint64_t out[3]);
 /* The elementary functions of the path as this library evaluates them (raytracer_amd/csrc/rtx_math.h; the reference calls
- * the platform libm): fn 0 powf(x, y), 1 expf(x), 2 sinf, 3 cosf, 4 tanf, 5 asinf, 6 acosf, 7 atan2f(x, y); host arrays
+ * the platform libm): fn 0 powf(x, y), 1 expf(x), 2 sinf, 3 cosf, 4 tanf, 5 asinf, 6 acosf, 7 atan2f(x, y), 8 x / 255 for
+ * x = 0 ... 255 (the texel conversion, which must equal the IEEE division); host arrays
  * of n values. on_device = 0 evaluates on the host side of the library (no GPU needed), 1 inside a kernel: the tests hold
  * both, bit for bit, to the CPU oracle's evaluation of the same source. */
 int rtx_debug_math(int fn, const float* x, const float* y, size_t n, float* out, int on_device);

@@ -562,17 +562,14 @@ __device__ __forceinline__ bool light_sample_dir(const DevLight& L, f3 P, float 
     return true;
 }
 __device__ __forceinline__ void light_sample_terms(const DevLight& L, float dist, DirInfo& si) {
-    const f3 intensity = ld3(L.intensity);
-    const float att_factor = (L.attenuation == 0.0f) ? 1.0f : L.attenuation * L.attenuation;
     if (L.size <= 0.0f) {
+        const f3 intensity = ld3(L.intensity);
+        const float att_factor = (L.attenuation == 0.0f) ? 1.0f : L.attenuation * L.attenuation;
         si.mult = intensity / (att_factor * dist * dist);
         si.prob = 1.0f;
     } else {
-        const float area = 4.0f * PI_F * L.size * L.size;
-        const float pdfArea = 2.0f / area;
-        const f3 radiance = intensity / (PI_F * L.size * L.size);
-        si.mult = radiance / att_factor;
-        si.prob = pdfArea;
+        si.mult = ld3(L.radAtt);   // radiance / att_factor with radiance = intensity / (pi size^2): DevLight, layout.h
+        si.prob = L.pdfArea;       // 2 / (4 pi size^2)
     }
     si.dist = dist;
     si.lobe = LOBE_ALL;
@@ -613,12 +610,8 @@ __device__ __forceinline__ void light_get_sample_info(const DevLight& L, f3 P, f
     const f3 nL = safe_normalize3(hit - position);
     const float cosLight = fmaxf(0.0f, dot3(-nL, d));
     if (cosLight <= 0.0f) return;
-    const float area = 4.0f * PI_F * L.size * L.size;
-    const float pdfArea = 2.0f / area;
-    const f3 radiance = intensity / (PI_F * L.size * L.size);
-    const float att_factor = (L.attenuation == 0.0f) ? 1.0f : L.attenuation * L.attenuation;
-    si.mult = radiance / att_factor;
-    si.prob = pdfArea;
+    si.mult = ld3(L.radAtt);
+    si.prob = L.pdfArea;
     si.dist = t;
     si.lobe = LOBE_ALL;
 }

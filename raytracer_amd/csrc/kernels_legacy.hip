@@ -757,7 +757,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void legacy_kernel(DevScene scArg, DevC
                         st.L = (hasBackground ? backplate : envLight) + bgEmit;
                     } else if (h.slot < -1) {   // a renderable light in front of the geometry: :613-624
                         SurfHit sl;
-                        resolve_light(sc, ray, h, sl);
+                        resolve_light(sc.lights, ray, h, sl);
                         primaryDist = len3(sl.p - rorg);
                         const DevLight& light = sc.lights[sl.light];
                         st.L = ld3(light.intensity) / (PI_F * light.size * light.size);

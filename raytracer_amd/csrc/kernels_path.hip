@@ -120,13 +120,37 @@ __global__ void raygen_kernel(DevCamera cam, PathPool pool, const int* __restric
 #endif
 // (the instantiations with the microfacet / Phong forms compiled in spill 36-74 registers at three waves, yet two waves
 // are slower: C3 scene through them, 32 spp: 96-105 ms against 110-112; the plain form: 91)
-template <bool MICRO, bool PHOT, bool PHONG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES_PER_EU))) void shade_kernel(DevScene sc, DevCamera cam, PathPool pool, DevPhotonMap pm,
+// LDSTAB: the scene's object, material and texture-map tables are copied to LDS when the block starts (they are small: 22 + 17 + 3
+// records for cerealBar.xml) and the shading body reads them there. A vertex reaches its texels through hit -> triangle ->
+// object -> material -> texture map -> texel, each step a memory round trip the wave waits out; the kernel waits on memory for
+// two thirds of its time, and three of those six steps are lookups in these tables.
+#define SHADE_LDS_OBJS 64
+#define SHADE_LDS_MTLS 32
+#define SHADE_LDS_TEX 8
+template <class T>
+__device__ __forceinline__ void shade_copy_table(T* dst, const T* src, int count) {
+    const uint32_t words = (uint32_t)count * (uint32_t)(sizeof(T) / 4u);
+    for (uint32_t k = threadIdx.x; k < words; k += blockDim.x) reinterpret_cast<uint32_t*>(dst)[k] = reinterpret_cast<const uint32_t*>(src)[k];
+}
+template <bool MICRO, bool PHOT, bool PHONG, bool LDSTAB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES_PER_EU))) void shade_kernel(DevScene scArg, DevCamera cam, PathPool pool, DevPhotonMap pm,
                                                     SegQ qIn, const uint32_t* __restrict__ queueIn, uint32_t n, int bounce,
                                                     int maxBounces, unsigned long long seed, int sBase, int S,
                                                     const int* __restrict__ pixels, SegQ qOut, uint32_t* __restrict__ queueOut,
                                                     SegQ qShadow, SegQ qNee) {
     __shared__ uint32_t qtab[SEGQ_TABLE_WORDS];
+    __shared__ ObjRec sObjs[LDSTAB ? SHADE_LDS_OBJS : 1];
+    __shared__ DevMaterial sMtls[LDSTAB ? SHADE_LDS_MTLS : 1];
+    __shared__ DevTexMap sTex[LDSTAB ? SHADE_LDS_TEX : 1];
+    DevScene sc = scArg;
+    if (LDSTAB) {   // (the launch wrapper has checked that the tables fit)
+        shade_copy_table(sObjs, scArg.objs, scArg.n_objs);
+        shade_copy_table(sMtls, scArg.mtls, scArg.n_mtls);
+        shade_copy_table(sTex, scArg.texmaps, scArg.n_texmaps);
+        sc.objs = sObjs;
+        sc.mtls = sMtls;
+        sc.texmaps = sTex;
+    }
     segq_load_table(qIn, qtab);
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -142,7 +166,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
         // a hit that the reference's box tests would have culled (lean extend kernel: not checked there): the vertex is left
         // alone and the path goes to the general tail kernel, which traces its ray again (rtx_render.cpp)
         bool culled = false;
-        if (pool.cullPaths && hitSlot >= 0 && !ref_reaches_triangle<false>(sc, ray, hitSlot, hv.x)) {
+        if (pool.cullPaths && hitSlot >= 0 && !ref_reaches_triangle<false>(scArg, ray, hitSlot, hv.x)) {
             const uint32_t k = atomicAdd(&pool.totals[4], 1u);
             if (k < RTX_CULL_CAP) {
                 pool.cullPaths[k] = slot;
@@ -153,7 +177,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
         // and leaves the vertex's record at index i of pool.neeCtx
         if (!culled)
             alive = shade_body<MICRO, false, PHOT, PHONG, true>(sc, cam, pool, pm, slot, ray, HitT{hv.x, hv.y, hv.z, hitSlot}, bounce, maxBounces,
-                                                                seed, sBase, S, pixels, qShadow, i, &qNee);
+                                                                seed, sBase, S, pixels, qShadow, i, &qNee, scArg.lights);
     }
     // ---- surviving paths -> next queue ----
     const uint32_t q = segq_append(qOut, alive, 1u);
@@ -532,9 +556,14 @@ uint32_t launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& 
                       hipStream_t stream) {
     if (!n) return 0;
     const uint32_t grid = (n + 255) / 256;
+    const bool ldsTab = sc.n_objs <= SHADE_LDS_OBJS && sc.n_mtls <= SHADE_LDS_MTLS && sc.n_texmaps <= SHADE_LDS_TEX;
 #define RTX_LAUNCH_SHADE(M, P, G)                                                                                                    \
-    hipLaunchKernelGGL((shade_kernel<M, P, G>), dim3(grid), dim3(256), 0, stream, sc, cam, pool, pm, qIn, queueIn, n, bounce, maxBounces, \
-                       seed, sBase, S, pixels, qOut, queueOut, qShadow, pool.qN)
+    if (ldsTab)                                                                                                                      \
+        hipLaunchKernelGGL((shade_kernel<M, P, G, true>), dim3(grid), dim3(256), 0, stream, sc, cam, pool, pm, qIn, queueIn, n, bounce, maxBounces, \
+                           seed, sBase, S, pixels, qOut, queueOut, qShadow, pool.qN);                                                \
+    else                                                                                                                             \
+        hipLaunchKernelGGL((shade_kernel<M, P, G, false>), dim3(grid), dim3(256), 0, stream, sc, cam, pool, pm, qIn, queueIn, n, bounce, maxBounces, \
+                           seed, sBase, S, pixels, qOut, queueOut, qShadow, pool.qN)
     // materialKinds: bit 0 = the scene holds MtlMicrofacet, bit 1 = MtlPhong; a caustics map selects the gather
     switch ((materialKinds & 3) | (pm.n > 0 ? 4 : 0)) {
         case 0: RTX_LAUNCH_SHADE(false, false, false); break;

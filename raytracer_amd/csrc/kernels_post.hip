@@ -201,6 +201,7 @@ __global__ void math_probe_kernel(int fn, const float* __restrict__ x, const flo
         case 4: r = rtx_tanf(x[i]); break;
         case 5: r = rtx_asinf(x[i]); break;
         case 6: r = rtx_acosf(x[i]); break;
+        case 8: r = rtx_unorm8(x[i]); break;
         default: r = rtx_atan2f(x[i], y[i]); break;
     }
     out[i] = r;

@@ -231,7 +231,7 @@ __global__ void expand_hits_kernel(DevScene sc, const float4* __restrict__ rays,
     if (h.slot != -1) {
         SurfHit s;
         if (h.slot >= 0) resolve_triangle(sc, r, h, s);
-        else resolve_light(sc, r, h, s);
+        else resolve_light(sc.lights, r, h, s);
         o.obj = s.obj;
         o.face = s.face;
         o.mtl_id = s.mtlID;

@@ -107,6 +107,13 @@ struct DevLight {
     float size;
     float intensity[3];
     float attenuation;
+    // Terms of PointLight::GenerateSample / GetSampleInfo that depend on the light alone (Shading.cpp:154-160, 198-204), formed
+    // once at scene creation by the same fp32 operations in the same order (rtx_api.cpp): radiance = intensity / (pi size^2),
+    // radAtt = radiance / attenuation^2 (attenuation 0 counts as 1), pdfArea = 2 / (4 pi size^2). Sphere lights only (size > 0).
+    float radiance[3];
+    float pdfArea;
+    float radAtt[3];
+    float pad;
 };
 
 // Everything a kernel needs, passed by value as a kernel argument (lives in SGPRs / kernarg segment).
@@ -119,7 +126,7 @@ struct DevScene {
     const DevMaterial* mtls;
     const DevTexMap* texmaps;
     uint32_t root;          // child reference of the root (a leaf reference for tiny scenes)
-    int n_tris, n_nodes, n_objs, n_lights, n_mtls;
+    int n_tris, n_nodes, n_objs, n_lights, n_mtls, n_texmaps;
     float bounds[6];        // rootNode.GetChildBoundBox()
     DevLight lights[8];
     float env[3]; int env_tex;

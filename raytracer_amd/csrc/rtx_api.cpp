@@ -221,12 +221,24 @@ int rtx_scene_create(const rtx_scene_desc* desc, rtx_scene** out) {
     }
     CHECK_RC(upload(s, mtls, &d.mtls));
     d.n_mtls = desc->n_materials;
+    d.n_texmaps = desc->n_texmaps;
     d.n_lights = desc->n_lights;
     for (int i = 0; i < desc->n_lights; ++i) {
         std::memcpy(d.lights[i].pos, desc->lights[i].position, 12);
         std::memcpy(d.lights[i].intensity, desc->lights[i].intensity, 12);
         d.lights[i].size = desc->lights[i].size;
         d.lights[i].attenuation = desc->lights[i].attenuation;
+        DevLight& L = d.lights[i];
+        if (L.size > 0.0f) {   // (this file is built with -ffp-contract=off like the kernels: the same bits as the expressions in bsdf.h)
+            const float PI_F = 3.14159265358979323846f;
+            const float area = 4.0f * PI_F * L.size * L.size;
+            L.pdfArea = 2.0f / area;
+            const float att_factor = (L.attenuation == 0.0f) ? 1.0f : L.attenuation * L.attenuation;
+            for (int k = 0; k < 3; ++k) {
+                L.radiance[k] = L.intensity[k] / (PI_F * L.size * L.size);
+                L.radAtt[k] = L.radiance[k] / att_factor;
+            }
+        }
     }
     if (!texOK(desc->environment_tex) || !texOK(desc->background_tex)) {
         rtx_scene_destroy(s);
@@ -318,7 +330,7 @@ int rtx_debug_queue_layout(uint32_t producer_blocks, uint32_t block_threads, uin
 }
 
 int rtx_debug_math(int fn, const float* x, const float* y, size_t n, float* out, int on_device) {
-    if (fn < 0 || fn > 7 || (n && (!x || !y || !out))) return rtx_fail(RTX_ERR_INVALID, "bad argument");
+    if (fn < 0 || fn > 8 || (n && (!x || !y || !out))) return rtx_fail(RTX_ERR_INVALID, "bad argument");
     if (n > 0x7FFFFFFFull) return rtx_fail(RTX_ERR_TOO_LARGE, "too many values");
     if (!on_device) {   // the host side of this library (make_dev_camera evaluates rtx_tanf there)
         for (size_t i = 0; i < n; ++i) {
@@ -330,6 +342,7 @@ int rtx_debug_math(int fn, const float* x, const float* y, size_t n, float* out,
                 case 4: out[i] = rtx_tanf(x[i]); break;
                 case 5: out[i] = rtx_asinf(x[i]); break;
                 case 6: out[i] = rtx_acosf(x[i]); break;
+                case 8: out[i] = rtx_unorm8(x[i]); break;
                 default: out[i] = rtx_atan2f(x[i], y[i]); break;
             }
         }

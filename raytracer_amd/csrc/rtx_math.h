@@ -48,6 +48,18 @@ RTX_MATH_FN double rtx_u2d(uint64_t u) {
     return d;
 }
 
+// ---- x / 255 for an 8-bit texel value -------------------------------------------------------------------------------
+// The float the IEEE division (float)x / 255.0f gives, for x = 0, 1, ... 255 and for those values only: the product with the
+// rounded reciprocal, corrected once by its exact residual (Markstein's step). tests/test_math_cpu.py checks all 256 values
+// against the division, in exact rational arithmetic and as compiled; a kernel pays 3 instructions for it instead of the 11
+// of the general division, and a bilinear texture tap makes twelve of them.
+RTX_MATH_FN float rtx_unorm8(float x) {
+    const float rc = 0x1.010102p-8f;   // the float nearest to 1 / 255
+    const float q = x * rc;
+    const float r = fmaf(-255.0f, q, x);
+    return fmaf(r, rc, q);
+}
+
 // ---- 2^t for a double t, rounded to float (shared by powf and expf) ----------------------------------------------------
 // k = nearest integer, r = t - k in [-1/2, 1/2], 2^r by its Taylor polynomial of degree 8 (truncation below 2^-32), the
 // power of two applied as an exact factor; the conversion to float does the one rounding (and the gradual underflow).

@@ -104,7 +104,11 @@ template <bool MICRO, bool TAIL, bool PHOT = true, bool PHONG = true, bool SPLIT
 __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pmArg,
                                            uint32_t slot, const RayT& ray, const HitT& h, int bounce, int maxBounces,
                                            unsigned long long seed, int sBase, int S, const int* __restrict__ pixels,
-                                           const SegQ& qShadow, uint32_t neeIndex = 0u, const SegQ* qNee = nullptr) {
+                                           const SegQ& qShadow, uint32_t neeIndex = 0u, const SegQ* qNee = nullptr,
+                                           const DevLight* lightsArg = nullptr) {
+    // the lights, read where the kernel's argument holds them: shade_kernel shades with a copy of the scene descriptor whose
+    // table pointers lead to LDS, and an array indexed at run time would keep that whole copy in scratch memory
+    const DevLight* lights = lightsArg ? lightsArg : sc.lights;
     DevPhotonMap pm = pmArg;
     if (!PHOT) pm.n = 0;   // every `pm.n > 0` below folds to false
     bool alive = false;
@@ -121,7 +125,9 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
             m4 = pool.medium[slot];
         }
         f3 L = mk3(L4.x, L4.y, L4.z);
+#ifndef RTX_ABLATE_RESOLVE   // (RTX_ABLATE_*: timing-only builds of tools/build_variant.sh that leave a part of the body out; wrong images)
         if (bounce > 0) resolve_add(pool, slot, sc.n_lights, pm.n > 0, L);   // the NEE of the previous vertex (its shadow results are in)
+#endif
         f3 beta = mk3(b4.x, b4.y, b4.z);
         float lastPdf = b4.w;
         uint32_t flags = __float_as_uint(m4.w);
@@ -158,7 +164,7 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
             }
             SurfHit sh;
             if (h.slot >= 0) resolve_triangle(sc, ray, h, sh);
-            else resolve_light(sc, ray, h, sh);
+            else resolve_light(lights, ray, h, sh);
             const float hitDist = len3(sh.p - rorg);
             if ((flags & PF_INSIDE_MEDIUM) && hitDist > 0.0f) beta = apply_absorption(beta, mediumAbs, hitDist);
 
@@ -167,7 +173,9 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
                 const int mi = sc.objs[sh.obj].material;
                 if (mi >= 0) mtl = &sc.mtls[mi];
             }
+#ifndef RTX_ABLATE_BUMP
             if (mtl) apply_bump(sc, *mtl, sh);
+#endif
             SampCtx sx;
             sx.P = sh.p;
             sx.V = -normalized3(rdir);
@@ -188,8 +196,8 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
             }
 
             if (sh.light >= 0) {   // :410-439
-                const DevLight& light = sc.lights[sh.light];
-                const f3 emitted = ld3(light.intensity) / (PI_F * light.size * light.size);
+                const DevLight& light = lights[sh.light];
+                const f3 emitted = light.size > 0.0f ? ld3(light.radiance) : ld3(light.intensity) / (PI_F * light.size * light.size);
                 float lightPdfSA = 0.0f;
                 if (flags & PF_HAS_PREV) {
                     const float4 pp = pool.prevP[slot];
@@ -231,7 +239,11 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
                 const f3 cN = micro ? mctx.N : ctx.N;
                 const bool behindToo = wantCaustic || (micro ? mctx.pt > 0.0f : luma1(ctx.transColor) > 0.0f);
                 uint32_t lightMask = 0u;
+#ifdef RTX_ABLATE_NEE
+                for (int l0 = 0; l0 < 0; l0 += 4) {
+#else
                 for (int l0 = 0; l0 < sc.n_lights; l0 += 4) {
+#endif
                     f3 ld[4];
                     float dd[4];
                     unsigned long long bal[4];
@@ -243,13 +255,18 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
                         ld[k] = mk3(0.0f);
                         dd[k] = 0.0f;
                         if (l < sc.n_lights) {
-                            const DevLight& light = sc.lights[l];
+                            const DevLight& light = lights[l];
                             const float u1 = sx.rnd(DIM_LIGHT0 + 2 * l), u2 = sx.rnd(DIM_LIGHT0 + 2 * l + 1);
                             if (light_sample_dir(light, sx.P, u1, u2, ld[k], dd[k])) {
                                 DirInfo li;
                                 light_sample_terms(light, dd[k], li);
-                                if (li.prob > 0.0f && max3c(li.mult) > 0.0f)   // (dir is normalised twice on its way into GetSampleInfo: RayCaster.cpp:475, Shading.cpp:535)
-                                    surv = behindToo || dot3(cN, safe_normalize3(safe_normalize3(ld[k]))) > 0.0f;
+                                if (li.prob > 0.0f && max3c(li.mult) > 0.0f) {
+                                    // the sign of N . dir, where dir is the sampled direction normalised twice more on its way into
+                                    // GetSampleInfo (RayCaster.cpp:475, Shading.cpp:535). ld[k] is a unit vector already: the two
+                                    // normalisations move the product by a few 1e-7 at most, so away from zero its own sign decides
+                                    const float d0 = dot3(cN, ld[k]);
+                                    surv = behindToo || d0 > 1e-5f || (d0 >= -1e-5f && dot3(cN, safe_normalize3(safe_normalize3(ld[k]))) > 0.0f);
+                                }
                             }
                         }
                         if (surv) lightMask |= 1u << l;
@@ -279,7 +296,7 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
                 }
             } else {
                 for (int l = 0; l < sc.n_lights; ++l) {
-                    const DevLight& light = sc.lights[l];
+                    const DevLight& light = lights[l];
                     f3 ldir;
                     DirInfo li;
                     float4 contrib = make_float4(0.0f, 0.0f, 0.0f, -1.0f);

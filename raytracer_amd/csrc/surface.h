@@ -17,7 +17,7 @@ __device__ __forceinline__ f3 tex_texel(const DevTexMap& tm, int x, int y) {
     const size_t i = (size_t)y * tm.width + x;
     if (tm.format == RTX_TEX_RGB8) {
         const uchar4 c = reinterpret_cast<const uchar4*>(tm.texels)[i];
-        return mk3((float)c.x / 255.0f, (float)c.y / 255.0f, (float)c.z / 255.0f);
+        return mk3(rtx_unorm8((float)c.x), rtx_unorm8((float)c.y), rtx_unorm8((float)c.z));   // = (float)c.x / 255.0f ... bit for bit
     }
     const float4 c = reinterpret_cast<const float4*>(tm.texels)[i];
     return mk3(c.x, c.y, c.z);
@@ -53,6 +53,9 @@ __device__ __forceinline__ f3 xf_vec3(const float* M, f3 p) {
                M[8] * p.x + M[9] * p.y + M[10] * p.z);
 }
 __device__ __forceinline__ f3 tex_eval(const DevScene& sc, int tex, f3 uvw) {
+#ifdef RTX_ABLATE_TEX
+    return mk3(0.5f);
+#endif
     const DevTexMap& tm = sc.texmaps[tex];
     return tex_eval_raw(tm, xf_point3(tm.xf, uvw));
 }
@@ -216,9 +219,9 @@ __device__ __forceinline__ void resolve_triangle(const DevScene& sc, const RayT&
 }
 
 // HitInfo of a light hit: Shading.cpp:78-84 on top of HitInfo::Init (uvw = 0.5 stand-in)
-__device__ __forceinline__ void resolve_light(const DevScene& sc, const RayT& r, const HitT& h, SurfHit& s) {
+__device__ __forceinline__ void resolve_light(const DevLight* lights, const RayT& r, const HitT& h, SurfHit& s) {
     const int li = -2 - h.slot;
-    const DevLight& L = sc.lights[li];
+    const DevLight& L = lights[li];
     const f3 dir = mk3(r.dx, r.dy, r.dz);
     s.t = h.t;
     s.p = mk3(r.ox, r.oy, r.oz) + dir * h.t;

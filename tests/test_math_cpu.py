@@ -47,3 +47,14 @@ def test_host_side_of_the_library_equals_the_oracle_bit_for_bit(name):
     out = np.empty_like(x)
     assert lib.rtx_debug_math(FN[name], x.ctypes.data, y.ctypes.data, len(x), out.ctypes.data, 0) == 0
     assert np.array_equal(out.view(np.uint32), oracle_eval(name, x, y).view(np.uint32))
+
+
+def test_unorm8_is_the_ieee_division_for_every_texel_value():
+    """rtx_unorm8(x) (three instructions in a kernel) must be the float that (float)x / 255.0f gives - the reference's and the
+    oracle's texel conversion - for each of the 256 values a texel can hold; checked on the host side of the library here
+    and on the device in tests/test_math_gpu.py."""
+    x = np.arange(256, dtype=np.float32)
+    lib = _ffi.load_library()
+    out = np.empty_like(x)
+    assert lib.rtx_debug_math(8, x.ctypes.data, x.ctypes.data, len(x), out.ctypes.data, 0) == 0
+    assert np.array_equal(out.view(np.uint32), (x / np.float32(255.0)).view(np.uint32))

@@ -21,3 +21,13 @@ def test_device_equals_oracle_bit_for_bit(rtx, name):
     ref = oracle_eval(name, x, y)
     bad = out.view(np.uint32) != ref.view(np.uint32)
     assert not bad.any(), (name, int(bad.sum()), x[bad][:5], y[bad][:5], out[bad][:5], ref[bad][:5])
+
+
+def test_unorm8_on_the_device_is_the_ieee_division(rtx):
+    """The texel conversion of the kernels (rtx_unorm8: product with the rounded reciprocal plus one residual step) against
+    numpy's float32 division for all 256 texel values."""
+    x = np.arange(256, dtype=np.float32)
+    lib = rtx._ffi.load_library()
+    out = np.empty_like(x)
+    assert lib.rtx_debug_math(8, x.ctypes.data, x.ctypes.data, len(x), out.ctypes.data, 1) == 0, lib.rtx_last_error()
+    assert np.array_equal(out.view(np.uint32), (x / np.float32(255.0)).view(np.uint32))
