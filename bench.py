@@ -154,7 +154,7 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
-    agg = dict(rays=0, ext_rays=0, extend_ms=0.0, shadow_ms=0.0, shade_ms=0.0, nee_ms=0.0, launches=0, shadow_rays=0)
+    agg = dict(rays=0, ext_rays=0, extend_ms=0.0, shadow_ms=0.0, shade_ms=0.0, nee_ms=0.0, launches=0, shadow_rays=0, vertices=0, shadow_segments=0)
     for _ in range(a.steps):
         st = step()
         agg["rays"] += st["rays_primary"] + st["rays_bounce"] + st["rays_shadow"]
@@ -165,6 +165,8 @@ def main():
         agg["shade_ms"] += st["shade_ms"]
         agg["nee_ms"] += st["nee_ms"]
         agg["launches"] += st["extend_launches"]
+        agg["vertices"] += st["vertices"]
+        agg["shadow_segments"] += st["shadow_segments"]
     sync()
     dt = time.perf_counter() - t0
 
@@ -179,8 +181,36 @@ def main():
     if rank == 0:
         res = ra.film_resolve(film, cam)
         finite = bool(np.isfinite(res["linear"]).all())
-        achieved = agg["ext_rays"] * bytes_per_ray / (agg["extend_ms"] * 1e-3) / 1e9 if agg["extend_ms"] > 0 else 0.0
-        traffic, traffic_src = measured_traffic(a, world)
+        default_cfg = (not a.legacy and a.tri_scale == 1.0 and a.width == 1920 and a.height == 1080 and a.spp == 128 and a.max_bounces == 64 and
+                       world == 1)
+        meas = Measured(default_cfg)
+        # ---- roofline of the kernels that make up the frame (algorithmic bytes per unit of work) ----
+        frames = a.steps
+        kernels = {}
+        ext = roofline_entry("extend_kernel", "ray", agg["ext_rays"], bytes_per_ray, agg["extend_ms"], frames,
+                             meas.traffic("extend_kernel<false"))
+        ext.update({"algorithmic_bytes_per_launch": bytes_per_ray * agg["ext_rays"] / max(1, agg["launches"]),
+                    "bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
+                    "avg_launch_ms": agg["extend_ms"] / max(1, agg["launches"]), "launches": agg["launches"],
+                    "extend_Mrays_s": agg["ext_rays"] / max(1e-9, agg["extend_ms"]) / 1e3,
+                    "traffic": meas.traffic_per_launch("extend_kernel<false"), "traffic_source": meas.traffic_src,
+                    "limiter": meas.limiter("extend_kernel<false")})
+        kernels["extend"] = ext
+        if not a.legacy:
+            # shade: 340 B per path vertex (2 x 64 B path state, 3 x 32 B vertex attributes, 64 B material, <= 3 x 16 B texture taps);
+            # since round 3 the light loop's lobe evaluation runs in nee_kernel: the two launches together are the "shade" of 8(d)
+            sh = roofline_entry("shade_kernel + nee_kernel", "path vertex", agg["vertices"], 340.0, agg["shade_ms"], frames,
+                                meas.traffic("shade_kernel<", "nee_kernel<"))
+            sh["nee_ms_per_frame"] = agg["nee_ms"] / frames
+            sh["limiter"] = meas.limiter("shade_kernel<")
+            kernels["shade"] = sh
+            hops_c = max(1, stc["rays_shadow"])
+            bytes_per_hop = 32 + 16 + stc["shadow_nodes"] / hops_c * info["node_bytes"] + stc["shadow_tris"] / hops_c * info["tri_bytes"]
+            sw = roofline_entry("shadow_kernel", "shadow hop", agg["shadow_rays"], bytes_per_hop, agg["shadow_ms"], frames,
+                                meas.traffic("shadow_kernel<false, false, false"))
+            sw.update({"nodes_per_hop": stc["shadow_nodes"] / hops_c, "tris_per_hop": stc["shadow_tris"] / hops_c,
+                       "segments_per_frame": agg["shadow_segments"] / frames, "limiter": meas.limiter("shadow_kernel<false, false, false")})
+            kernels["shadow"] = sw
         out = {
             "metric": "Mrays/s, cerealBar 1080p 128spp path traced (all ray segments: primary + bounce + shadow hops)",
             "value": rays_all / dt_max / 1e6,
@@ -202,50 +232,119 @@ def main():
             "rays_per_frame": rays_all / a.steps,
             "image_finite": finite,
             "mean_linear": float(res["linear"].mean()),
-            "roofline": {"bound": "hbm", "kernel": "extend_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": bytes_per_ray * agg["ext_rays"] / max(1, agg["launches"]),
-                         "bytes_per_ray": bytes_per_ray, "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
-                         "avg_launch_ms": agg["extend_ms"] / max(1, agg["launches"]), "launches": agg["launches"],
-                         "extend_Mrays_s": agg["ext_rays"] / max(1e-9, agg["extend_ms"]) / 1e3,
-                         "limiter": measured_limiter()},
+            # the dominant kernel. `bound` names the roofline its algorithmic bytes are priced against (HBM: nothing on this path
+            # is a contraction); what holds it below that line is in `limiter` (PMC: divergence and memory latency)
+            "roofline": dict(ext, bound="hbm"),
+            "roofline_kernels": kernels,
+            "library_sha256": meas.sha,
             "kernel_ms_per_frame_rank0": {"extend": agg["extend_ms"] / a.steps, "shadow": agg["shadow_ms"] / a.steps,
                                           "shade": agg["shade_ms"] / a.steps, "nee": agg["nee_ms"] / a.steps},
         }
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, cam, a)
+        if world == 1 and not a.no_cpu_baseline and a.legacy:
+            out["cpu_baseline"], _ = cpu_baseline(sd, cam, a)
+        elif world == 1 and not a.no_cpu_baseline:
+            # the reference's box culls switched on (RTX_AMD_BOX_CULLS=1: the mode whose every sample is the oracle's, DESIGN.md 4
+            # item 8): its frame time beside the default's, and its film against the CPU render below
+            os.environ["RTX_AMD_BOX_CULLS"] = "1"
+            step()
+            sync()
+            t1 = time.perf_counter()
+            step()
+            sync()
+            exact_ms = (time.perf_counter() - t1) * 1e3
+            del os.environ["RTX_AMD_BOX_CULLS"]
+            res_exact = ra.film_resolve(film, cam)
+            out["exact_mode"] = {"switch": "RTX_AMD_BOX_CULLS=1", "ms_per_step": exact_ms, "steps": 1}
+            out["cpu_baseline"], cpu_img = cpu_baseline(sd, cam, a)
+            if a.cpu_spp in (0, a.spp):   # equal spp: the same samples on both sides
+                out["rmse_vs_cpu"] = rmse_vs_cpu(cpu_img, res_exact["linear"], res["linear"], W, H, a)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def measured_traffic(a, world):
-    """HBM-side bytes per extend launch from the PMC passes of this same workload (tools/pmc_traffic.sh, committed under
-    profiles/): 2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md "HBM") + WRITE_SIZE over the
-    launches. A PMC run cannot be nested inside this process, so the figure is the committed measurement; it is
-    reported only when this run is the configuration it was measured on."""
-    rel = next((r for r in ("profiles/r02/extend_traffic_c3.json", "profiles/r01/extend_traffic_c3.json") if os.path.exists(os.path.join(ROOT, r))), None)
-    path = os.path.join(ROOT, rel) if rel else ""
-    default = (not a.legacy and a.tri_scale == 1.0 and a.width == 1920 and a.height == 1080 and a.spp == 128 and a.max_bounces == 64 and
-               world == 1)
-    if not default or not os.path.exists(path):
-        return None, None
-    # the non-counting instantiation of the extend kernel (extend_kernel<false> in round 1, <false, XF, BOTH> since)
-    k = next((v for n, v in json.load(open(path))["kernels"].items() if n.startswith("extend_kernel<false")), None)
-    if not k or not k["dispatches"]:
-        return None, None
-    return (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 / k["dispatches"], rel
+def roofline_entry(kernel, unit, units, bytes_per_unit, ms, frames, traffic_bytes):
+    """achieved = algorithmic bytes / HIP-event time of the kernel's launches (events recorded by the library on the launch
+    stream); traffic_bytes: HBM-side bytes of the same launches over one frame from the committed PMC passes, or None."""
+    achieved = units * bytes_per_unit / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    e = {"kernel": kernel, "bound": "hbm", "unit": "GB/s", "achieved": achieved, "peak": HBM_PEAK_GBS, "frac": achieved / HBM_PEAK_GBS,
+         "work_unit": unit, "units_per_frame": units / max(1, frames), "algorithmic_bytes_per_unit": bytes_per_unit, "ms_per_frame": ms / max(1, frames)}
+    if traffic_bytes is not None:
+        e["traffic_bytes_per_unit"] = traffic_bytes / max(1.0, units / max(1, frames))
+    return e
 
 
-def measured_limiter():
-    """What the PMC passes say holds the extend kernel back (committed measurement, not collected by this run)."""
-    path = os.path.join(ROOT, "profiles", "r02", "extend_limiter.json")
-    if not os.path.exists(path):
-        return None
-    j = json.load(open(path))
-    return {"what": "divergence + memory latency", "valu_issue_frac": j["valu_issue_frac_of_wave_time"],
-            "active_lanes_per_valu": j["active_lanes_per_valu"], "wait_frac": j["wait_any_frac"], "l2_hit": j["l2_hit"], "source": j["source"]}
+class Measured:
+    """Counter-side figures of this workload from the committed PMC passes (tools/pmc_traffic.sh, tools/pmc.sh: a PMC run cannot be
+    nested inside this process). They describe the kernels of ONE build: each file records the SHA-256 of the librtx_amd.so it
+    was measured on, and a figure is reported only when this run loads that same library and is the configuration it was
+    measured on - stale counters do not ride along."""
+
+    def __init__(self, default_cfg):
+        import hashlib
+        from raytracer_amd import _ffi
+        with open(_ffi.LIB_PATH, "rb") as f:
+            self.sha = hashlib.sha256(f.read()).hexdigest()
+        self.traffic_src = self.limiter_src = None
+        self.t = self.l = None
+        if not default_cfg:
+            return
+        for rel in ("profiles/r03/kernel_traffic_c3.json",):
+            path = os.path.join(ROOT, rel)
+            if os.path.exists(path):
+                j = json.load(open(path))
+                if j.get("library_sha256") == self.sha:
+                    self.t, self.traffic_src = j["kernels"], rel
+        for rel in ("profiles/r03/kernel_limiters.json",):
+            path = os.path.join(ROOT, rel)
+            if os.path.exists(path):
+                j = json.load(open(path))
+                if j.get("library_sha256") == self.sha:
+                    self.l, self.limiter_src = j["kernels"], rel
+
+    def _sum(self, prefixes):
+        if not self.t:
+            return None, 0
+        ks = [v for n, v in self.t.items() if any(n.startswith(p) for p in prefixes)]
+        if not ks:
+            return None, 0
+        # 2 x FETCH_SIZE: gfx950 tallies 128-B requests at 64 B (MI355X_MICROARCH.md "HBM")
+        return sum((2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 for k in ks), max(k["dispatches"] for k in ks)
+
+    def traffic(self, *prefixes):          # bytes per frame (the PMC pass runs one frame)
+        return self._sum(prefixes)[0]
+
+    def traffic_per_launch(self, *prefixes):
+        b, n = self._sum(prefixes)
+        return b / n if b is not None and n else None
+
+    def limiter(self, prefix):
+        if not self.l:
+            return None
+        k = next((v for n, v in self.l.items() if n.startswith(prefix)), None)
+        return dict(k, source=self.limiter_src) if k else None
+
+
+def rmse_vs_cpu(cpu_img, gpu_exact, gpu_default, W, H, a):
+    """The GPU film against the CPU render of the cpu_baseline leg, on the pixels both hold completely: the 14 x 14 interior
+    pixels of the sampled 16 x 16 buckets (tent filter, radius 1: an interior pixel receives samples of its own bucket only)."""
+    import numpy as np
+    m = np.zeros((H, W), bool)
+    for by in range(0, H, 16 * 8):
+        for bx in range(0, W, 16 * 8):
+            m[by + 1:min(by + 15, H - 1), bx + 1:min(bx + 15, W - 1)] = True
+    c = cpu_img.reshape(H, W, 3)[m].astype(np.float64)
+    mean_lum = float(c.mean())
+
+    def rel(g):
+        d = g.reshape(H, W, 3)[m].astype(np.float64) - c
+        return float(np.sqrt((d * d).mean()) / max(mean_lum, 1e-30))
+
+    return {"pixels": int(m.sum()), "spp": a.cpu_spp if a.cpu_spp > 0 else a.spp, "mean_luminance": mean_lum,
+            "rmse_over_mean_exact_mode": rel(gpu_exact), "rmse_over_mean_default": rel(gpu_default), "bar": 1e-5,
+            "note": "per-sample radiance is bit-identical in exact mode; the films differ by the order of their float sums. The default "
+                    "(lean kernels) omits the reference's box culls: about 2 samples in 10^7 end differently (DESIGN.md 4 item 8)"}
 
 
 def cpu_baseline(sd, cam, a):
@@ -265,10 +364,10 @@ def cpu_baseline(sd, cam, a):
                        shading_mode=_ffi.SHADING_LEGACY if a.legacy else _ffi.SHADING_PATH)
     r = osc.render(cam, rp, nthreads=threads, subset_stride=8)
     rays = r["rays"]["primary"] + r["rays"]["bounce"] + r["rays"]["shadow"]
-    return {"value": rays / r["seconds"] / 1e6, "unit": "Mrays/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
-            "sample": f"every 8th 16x16 bucket in x and y (1/64 of the frame) at {cpu_spp} spp, same scene/camera/sampler; "
-                      f"{rays} ray segments in {r['seconds']:.2f} s (+{build_s:.1f} s BVH build, untimed)",
-            "seconds": r["seconds"], "paths": r["rays"]["primary"]}
+    return ({"value": rays / r["seconds"] / 1e6, "unit": "Mrays/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
+             "sample": f"every 8th 16x16 bucket in x and y (1/64 of the frame) at {cpu_spp} spp, same scene/camera/sampler; "
+                       f"{rays} ray segments in {r['seconds']:.2f} s (+{build_s:.1f} s BVH build, untimed)",
+             "seconds": r["seconds"], "paths": r["rays"]["primary"]}, r["linear"])
 
 
 if __name__ == "__main__":

@@ -566,6 +566,17 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
     for (Node4& n : out.nodes)
         for (int i = 0; i < 4; ++i)
             if (n.child[i] != RTX_EMPTY_CHILD && ((n.pad[0] >> i) & 1u)) n.child[i] |= 0x40000000u;
+    // ... and the root reference itself (a shadow hop that starts with a known blocker - the blocker cache - looks at nothing
+    // but such subtrees from its first step on)
+    if (out.root != RTX_EMPTY_CHILD) {
+        bool trans = false;
+        if (out.root & RTX_LEAF_FLAG) {
+            const uint32_t first = (out.root & 0x7FFFFFFFu) >> 3, cnt = (out.root & 7u) + 1;
+            for (uint32_t k = 0; k < cnt; ++k) trans = trans || (out.tris[first + k].obj & TRI_OPAQUE) == 0u;
+        } else
+            trans = out.nodes[out.root].pad[1] != 0u;
+        if (trans) out.root |= 0x40000000u;
+    }
     return true;
 }
 

@@ -199,17 +199,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
 #endif
 // useTransmittance: bit 0 = Visible() with transmittance (else VisibleSimple), bit 1 = no early exit (parity checks)
 // CULL (lean kernel only): hops that end on a hit are checked against the reference's box tests (PathPool::cullShadows)
-template <bool XF, bool CULL = false>
+// Blocker cache (experiment, compiled in with -DRTX_BLOCKER_CACHE by tools/build_variant.sh; RTX_AMD_BLOCKER_CACHE=cells at run
+// time): a hash table over cells of shadow-ray origins x lights that remembers the opaque triangle which last blocked a ray from
+// that cell. Measured on the C3 frame (round 3): 45 % of the hops are blocked, but only 2.4 / 4.4 / 9.1 % of all hops find their
+// blocker in the cache with cells of 1/128, 1/512, 1/2048 of the scene (the occluders of this scene are millimetre-sized cereal
+// pieces: the triangle that blocks one ray seldom blocks its neighbour), and the candidate's fetch and test on the other hops
+// cost more: shadow 184-186 ms per frame against 162 without the code (173 with the code compiled in and the table off).
+// index of the entry for a shadow ray that starts at o towards light l:
+__device__ __forceinline__ uint32_t blocker_key(const DevScene& sc, const PathPool& pool, f3 o, uint32_t l) {
+    const int cx = (int)((o.x - sc.bounds[0]) * pool.blockerScale), cy = (int)((o.y - sc.bounds[1]) * pool.blockerScale),
+              cz = (int)((o.z - sc.bounds[2]) * pool.blockerScale);
+    uint32_t h = ((uint32_t)cx * 73856093u) ^ ((uint32_t)cy * 19349663u) ^ ((uint32_t)cz * 83492791u);
+    h = (h ^ (h >> 15)) * 8u + l;
+    return h & pool.blockerMask;
+}
+// COUNT: nodes visited and triangles tested are tallied (counters[3], [4]) - the instrumented build behind rtx_set_counters, which
+// gives the bench the algorithmic bytes of a shadow hop (48 + nodes x 64 + triangles x 48)
+template <bool XF, bool CULL = false, bool COUNT = false>
 #ifdef SHADOW_WAVES_PER_EU
 __attribute__((amdgpu_waves_per_eu(SHADOW_WAVES_PER_EU)))
 #endif
 __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, PathPool pool, SegQ q, int useTransmittance, uint2* spill,
-                                                            uint32_t chunk, const uint32_t* __restrict__ items) {
+                                                            uint32_t chunk, const uint32_t* __restrict__ items, unsigned long long* counters) {
     __shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
     const DevSceneT<XF> sc(scArg);
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
     TravStack st = make_trav_stack(&lds_stack[threadIdx.x], spill, gtid, gridDim.x * blockDim.x);
-    uint32_t hops = 0;
+    uint32_t hops = 0, nodeCount = 0, triCount = 0;
+#ifdef SHADOW_CACHE_STATS
+    uint32_t cacheHits = 0;
+#endif
     TravState s;
     s.cur = RTX_TRAV_DONE;
     s.sp = 0;
@@ -254,7 +273,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
             } else if (fin) {
                 bool next = true;
                 if (mode != 3) {
-                    intersect_lights(sc, s.r, s.best);
+                    intersect_lights(scArg, s.r, s.best);
                     float T;
                     if (shadow_hop_end(sc, o, d, maxDist, s.best, (useTransmittance & 1) != 0, hop, visibility, T)) {
                         pool.nee[(size_t)(code & 7u) * pool.capacity + (code >> 3)].w = T;
@@ -291,6 +310,32 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
                     mode = 0;
                     hops++;
                     active = true;
+                    // Blocker cache (lean scenes): the opaque triangle that last blocked a ray from this neighbourhood towards this
+                    // light is tested before anything else. If it blocks this ray too - a hit that decides the hop,
+                    // shadow_hit_decides - the lane starts where a traversal would have arrived after finding it: blocker known,
+                    // only subtrees with surfaces that let light through are left to look at (mode 1). The hop's answer is formed
+                    // by the same rules from there on, so the cache changes no result, whatever it holds.
+#ifdef RTX_BLOCKER_CACHE   // (variant builds only: measured not to pay on this scene, see the comment at blocker_key)
+                    if (!XF && pool.blockerCache && (useTransmittance & 2) == 0) {
+                        const int cand = pool.blockerCache[blocker_key(scArg, pool, o, code & 7u)];
+                        if (cand >= 0) {
+                            const float4* tris4 = reinterpret_cast<const float4*>(sc.tris);
+                            const float4 ta = tris4[(size_t)cand * 3 + 0], tb = tris4[(size_t)cand * 3 + 1], tc = tris4[(size_t)cand * 3 + 2];
+                            test_triangle(ta, tb, tc, s.r, RTX_HIT_FRONT_AND_BACK, (uint32_t)cand, sc.tris, s.best, s.bestPrim);
+                            if (s.best.slot >= 0 && shadow_hit_decides(scArg, s, maxDist, (useTransmittance & 1) != 0)) {
+#ifdef SHADOW_CACHE_STATS
+                                cacheHits++;
+#endif
+                                if ((useTransmittance & 1) != 0) {
+                                    mode = 1;
+                                    trav_skip_opaque(s, st);
+                                } else
+                                    s.cur = RTX_TRAV_DONE;   // VisibleSimple: any surface in front of the segment's end blocks
+                            } else
+                                trav_init(s, sc, RayT{o.x, o.y, o.z, d.x, d.y, d.z, maxDist});   // no help: a plain hop
+                        }
+                    }
+#endif
                 }
             }
         }
@@ -306,7 +351,8 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
                 if (atLeaf) {
 #if SHADOW_ANYHIT
                     const int before = s.best.slot;
-                    trav_leaf_test(s, sc, s.cur, RTX_HIT_FRONT_AND_BACK);
+                    const uint32_t nt = trav_leaf_test(s, sc, s.cur, RTX_HIT_FRONT_AND_BACK);
+                    if (COUNT) triCount += nt;
                     bool stop = false;   // the hop ends here: decided (VisibleSimple), or to be traced again
                     if (s.best.slot != before && (useTransmittance & 2) == 0 && mode != 2) {
                         const bool withT = (useTransmittance & 1) != 0;
@@ -316,9 +362,12 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
                                 mode = 3;
                                 stop = true;
                             }
-                        } else if (shadow_hit_decides(sc, s, maxDist, withT)) {
+                        } else if (shadow_hit_decides(scArg, s, maxDist, withT)) {
                             if (withT) mode = 1;
                             else stop = true;   // VisibleSimple: whatever the closest hit is, it lies in front of this one and blocks
+#ifdef RTX_BLOCKER_CACHE
+                            if (!XF && pool.blockerCache && hop == 0) pool.blockerCache[blocker_key(scArg, pool, o, code & 7u)] = s.best.slot;
+#endif
                         }
                     }
                     if (stop) {
@@ -334,6 +383,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
 #endif
                 }
             } else if (atInner) {
+                if (COUNT) nodeCount++;
                 trav_inner_step(s, sc, st);
 #if SHADOW_ANYHIT
                 if (mode == 1) trav_skip_opaque(s, st);
@@ -342,6 +392,13 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
         }
     }
     atomicAdd(&pool.rayCounters[0], (unsigned long long)hops);
+    if (COUNT) {
+        atomicAdd(&counters[3], (unsigned long long)nodeCount);
+        atomicAdd(&counters[4], (unsigned long long)triCount);
+    }
+#ifdef SHADOW_CACHE_STATS
+    atomicAdd(&pool.rayCounters[4], (unsigned long long)cacheHits);
+#endif
 }
 
 // ---- film (RayCaster.cpp:798-838) -----------------------------------------------------------------------------
@@ -582,15 +639,19 @@ void launch_shadow(const DevScene& sc, const LaunchCfg& cfg, const PathPool& poo
     if (!n) return;
     const uint32_t need = (n + TRAV_BLOCK - 1) / TRAV_BLOCK;
     const uint32_t grid = need < (uint32_t)cfg.gridBlocks ? need : (uint32_t)cfg.gridBlocks;
-    if (sc.has_xf)
-        hipLaunchKernelGGL(shadow_kernel<true>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, pool, q, useTransmittance, cfg.spill,
-                           segq_chunk(n, grid * (TRAV_BLOCK / 64)), (const uint32_t*)nullptr);
-    else if (pool.cullShadows)
-        hipLaunchKernelGGL((shadow_kernel<false, true>), dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, pool, q, useTransmittance, cfg.spill,
-                           segq_chunk(n, grid * (TRAV_BLOCK / 64)), (const uint32_t*)nullptr);
+#define RTX_LAUNCH_SHADOW(X, C, N)                                                                                                          \
+    hipLaunchKernelGGL((shadow_kernel<X, C, N>), dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, pool, q, useTransmittance, cfg.spill,     \
+                       segq_chunk(n, grid * (TRAV_BLOCK / 64)), (const uint32_t*)nullptr, cfg.counters)
+    if (sc.has_xf) {
+        if (cfg.counting) RTX_LAUNCH_SHADOW(true, false, true);
+        else RTX_LAUNCH_SHADOW(true, false, false);
+    } else if (pool.cullShadows)
+        RTX_LAUNCH_SHADOW(false, true, false);   // (the box-cull checks and the counters exclude each other: rtx_render.cpp)
+    else if (cfg.counting)
+        RTX_LAUNCH_SHADOW(false, false, true);
     else
-        hipLaunchKernelGGL(shadow_kernel<false>, dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, pool, q, useTransmittance, cfg.spill,
-                           segq_chunk(n, grid * (TRAV_BLOCK / 64)), (const uint32_t*)nullptr);
+        RTX_LAUNCH_SHADOW(false, false, false);
+#undef RTX_LAUNCH_SHADOW
 }
 // The chains the lean shadow kernel set aside (pool.cullShadows, their number in pool.totals[5]) through the general
 // kernel. The host does not know the number: a one-wave kernel turns it into an identity queue over the list and resets it,
@@ -611,8 +672,8 @@ __global__ void segq_identity_counted_kernel(SegQ q, uint32_t* count, uint32_t c
 }
 void launch_shadow_culled(const DevScene& scGeneral, const LaunchCfg& cfg, const PathPool& pool, const SegQ& qList, int useTransmittance) {
     hipLaunchKernelGGL(segq_identity_counted_kernel, dim3(1), dim3(64), 0, cfg.stream, qList, pool.totals + 5, RTX_CULL_CAP);
-    hipLaunchKernelGGL(shadow_kernel<true>, dim3(2), dim3(TRAV_BLOCK), 0, cfg.stream, scGeneral, pool, qList, useTransmittance, cfg.spill, 64u,
-                       (const uint32_t*)pool.cullShadows);
+    hipLaunchKernelGGL((shadow_kernel<true, false, false>), dim3(2), dim3(TRAV_BLOCK), 0, cfg.stream, scGeneral, pool, qList, useTransmittance, cfg.spill, 64u,
+                       (const uint32_t*)pool.cullShadows, cfg.counters);
 }
 void launch_film(const PathPool& pool, const rtx_film& film, const int* pixels, uint32_t nPix, int S, int W, int H, int filterType,
                  float filterRadius, int resetZ, float4* samplesOut, int sBase, int sppTotal, float radianceClamp, int nLights,

@@ -59,6 +59,12 @@ struct PathPool {
     // shadow_kernel) and handed to the general kernels. nullptr: not checked (RTX_AMD_BOX_CULLS=0, general scenes).
     uint32_t* cullPaths;    // path slots whose vertex was not shaded: their ray is traced again by the general tail kernel
     uint32_t* cullShadows;  // shadow queue entries whose chain is traced again by the general shadow kernel
+    // Blocker cache of the shadow kernel (kernels_path.hip): for a cell of shadow-ray origins and a light, the opaque triangle that
+    // last blocked such a ray. A hint only - whatever it holds, the kernel's answers are the same - so it is read and written
+    // without synchronisation and kept across launches and frames. nullptr: switched off.
+    int* blockerCache;      // blockerMask + 1 entries, -1 = empty
+    uint32_t blockerMask;
+    float blockerScale;     // cells per unit length
     uint32_t* counters;     // scratch counters ([8] adaptive refinement list)
     // per pixel (full frame)
     int* pixels;            // pixel list of the current round (padded to 64 with -1)

@@ -384,7 +384,7 @@ int rtx_scene_info(const rtx_scene* s, uint64_t counts[6], float bounds[6]) {
 int rtx_set_counters(rtx_scene* s, int enabled) {
     if (!s) return rtx_fail(RTX_ERR_INVALID, "scene is NULL");
     s->cfg.counting = enabled ? 1 : 0;
-    RTX_HIP(hipMemset(s->cfg.counters, 0, 3 * sizeof(unsigned long long)));
+    RTX_HIP(hipMemset(s->cfg.counters, 0, 8 * sizeof(unsigned long long)));
     return RTX_OK;
 }
 

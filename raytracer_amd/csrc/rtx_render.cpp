@@ -127,6 +127,25 @@ static int ensure_pool(rtx_scene* s, uint32_t slots, size_t framePixels, size_t 
     PA(cullShadows, RTX_CULL_CAP);
     if ((rc = pool_alloc(ph, &ph->qCull.ctl, SEGQ_WORDS)) != RTX_OK) return rc;
     PA(counters, 64);
+    // blocker cache of the shadow kernel (variant builds, -DRTX_BLOCKER_CACHE): 2^22 entries (16 MB), cells of 1/512 of the scene's
+    // largest extent; RTX_AMD_BLOCKER_CACHE=0 switches it off, =N sets the cells per extent
+    {
+        int cells = 0;   // off: the shipped shadow kernel does not read it (kernels_path.hip, blocker_key)
+#ifdef RTX_BLOCKER_CACHE
+        cells = 512;
+        if (const char* e = std::getenv("RTX_AMD_BLOCKER_CACHE")) cells = std::atoi(e);
+#endif
+        d.blockerCache = nullptr;
+        if (cells > 0 && !s->dev.has_xf) {
+            const float ext = std::max(s->dev.bounds[3] - s->dev.bounds[0], std::max(s->dev.bounds[4] - s->dev.bounds[1], s->dev.bounds[5] - s->dev.bounds[2]));
+            if (ext > 0.0f && ext < 1e30f) {
+                d.blockerMask = (1u << 22) - 1u;
+                d.blockerScale = (float)cells / ext;
+                PA(blockerCache, (size_t)d.blockerMask + 1);
+                if (hipMemset(d.blockerCache, 0xFF, ((size_t)d.blockerMask + 1) * sizeof(int)) != hipSuccess) return rtx_fail(RTX_ERR_HIP, "blocker cache clear failed");
+            }
+        }
+    }
     PA(pixels, ph->framePixels + 64);
     PA(pixelsNext, ph->framePixels + 64);
     if ((rc = pool_alloc(ph, &ph->pixelsBase, ph->framePixels + 64)) != RTX_OK) return rc;
@@ -334,7 +353,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     RTX_HIP(hipMemsetAsync(pool.rayCounters, 0, 8 * sizeof(unsigned long long), st));
     RTX_HIP(hipMemsetAsync(pool.totals, 0, 16 * sizeof(uint32_t), st));
     RTX_HIP(hipMemsetAsync(ph->qCull.ctl, 0, SEGQ_WORDS * sizeof(uint32_t), st));
-    if (s->cfg.counting) RTX_HIP(hipMemsetAsync(s->cfg.counters, 0, 3 * sizeof(unsigned long long), st));
+    if (s->cfg.counting) RTX_HIP(hipMemsetAsync(s->cfg.counters, 0, 8 * sizeof(unsigned long long), st));
     // queue counters are left at zero by every scan; a cancelled or failed call may have left some behind
     RTX_HIP(hipMemsetAsync(pool.qA.ctl, 0, SEGQ_WORDS * sizeof(uint32_t), st));
     RTX_HIP(hipMemsetAsync(pool.qB.ctl, 0, SEGQ_WORDS * sizeof(uint32_t), st));
@@ -536,9 +555,10 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     tm.flush();
     float total = 0.0f;
     (void)hipEventElapsedTime(&total, evTotal0, evTotal1);
-    unsigned long long rc2[4] = {0, 0, 0, 0};   // [0] shadow hops, [1] closest-hit rays traced inside tail_kernel
+    unsigned long long rc2[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // [0] shadow hops, [1] closest-hit rays traced inside tail_kernel, [4] blocker-cache hits (SHADOW_CACHE_STATS builds)
     RTX_HIP(hipMemcpy(rc2, pool.rayCounters, sizeof(rc2), hipMemcpyDeviceToHost));
     out.rays_shadow = rc2[0];
+    if (tm.trace && rc2[4]) std::fprintf(stderr, "[rtx trace] blocker cache: %llu of %llu shadow hops started from a cached blocker\n", rc2[4], rc2[0]);
     out.rays_extend = out.rays_primary + out.rays_bounce;   // traced by extend launches (the rest: tail / legacy kernel)
     out.rays_bounce += rc2[1];
     out.extend_ms = tm.ms[0];
@@ -547,10 +567,12 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     out.nee_ms = tm.ms[3];
     out.total_ms = total;
     if (s->cfg.counting) {
-        unsigned long long c[3];
+        unsigned long long c[5];
         RTX_HIP(hipMemcpy(c, s->cfg.counters, sizeof(c), hipMemcpyDeviceToHost));
         out.nodes_visited = c[0];
         out.tris_tested = c[1];
+        out.shadow_nodes = c[3];
+        out.shadow_tris = c[4];
     }
     if (stats) *stats = out;
     return RTX_OK;

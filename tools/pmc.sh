@@ -14,6 +14,6 @@ for s in sq1 sq2 tcp tcc; do
   rm -rf gpurun_out/pmc_${tag}_$s
   timeout -s KILL 240 rocprofv3 --pmc ${SETS[$s]} -d gpurun_out/pmc_${tag}_$s --output-format csv -- python3 bench.py $args > gpurun_out/pmc_${tag}_$s.log 2>&1 || { echo "pass $s failed"; tail -5 gpurun_out/pmc_${tag}_$s.log; exit 1; }
 done
-python3 tools/pmc_summary.py gpurun_out/pmc_${tag}_* | tee gpurun_out/pmc_${tag}_summary.txt
+python3 tools/pmc_summary.py --json gpurun_out/pmc_${tag}_limiters.json gpurun_out/pmc_${tag}_* | tee gpurun_out/pmc_${tag}_summary.txt
 # keep only the summaries (the raw per-dispatch CSVs are large)
 for s in sq1 sq2 tcp tcc; do rm -rf gpurun_out/pmc_${tag}_$s; done

@@ -1,7 +1,8 @@
 #!/bin/bash
 # The measurements a round commits under profiles/: the default bench line, the rocprofv3 kernel-trace summary of the
-# same command, and the extend kernel's HBM-side traffic (two --pmc passes). Run on the GPU box:
-#   tools/profile_round.sh TAG   ->  gpurun_out/bench_c3_TAG.json, bench_c3_kernel_stats_TAG.csv, extend_traffic.json
+# same command, the kernels' HBM-side traffic (two --pmc passes) and the PMC reading of what limits them. Run on the GPU box:
+#   tools/profile_round.sh TAG   ->  gpurun_out/bench_c3_TAG.json, bench_c3_kernel_stats_TAG.csv, kernel_traffic.json, pmc_TAG_limiters.json
+# (copy kernel_traffic.json -> profiles/rNN/kernel_traffic_c3.json and pmc_TAG_limiters.json -> profiles/rNN/kernel_limiters.json: bench.py reads them)
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 mkdir -p gpurun_out
@@ -13,6 +14,7 @@ f=$(find gpurun_out/prof_$tag -name '*kernel_stats.csv' | head -1)
 cp "$f" gpurun_out/bench_c3_kernel_stats_$tag.csv && rm -rf gpurun_out/prof_$tag
 grep '^{"metric"' gpurun_out/prof_$tag.log > gpurun_out/bench_c3_under_rocprof_$tag.json
 tools/pmc_traffic.sh || exit 1
+bash tools/pmc.sh $tag > /dev/null || exit 1
 python3 - "$tag" <<'PY'
 import json, sys
 j = json.load(open(f"gpurun_out/bench_c3_{sys.argv[1]}.json"))
