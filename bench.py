@@ -243,21 +243,22 @@ def main():
         if world == 1 and not a.no_cpu_baseline and a.legacy:
             out["cpu_baseline"], _ = cpu_baseline(sd, cam, a)
         elif world == 1 and not a.no_cpu_baseline:
-            # the reference's box culls switched on (RTX_AMD_BOX_CULLS=1: the mode whose every sample is the oracle's, DESIGN.md 4
-            # item 8): its frame time beside the default's, and its film against the CPU render below
-            os.environ["RTX_AMD_BOX_CULLS"] = "1"
+            # The timed frames above ran with the reference's box culls checked (the default: every sample is the oracle's,
+            # DESIGN.md 4 item 8). One frame without the checks (RTX_AMD_BOX_CULLS=0, the lean kernels alone) beside it: what the
+            # checks cost, and what leaving them out does to the image.
+            os.environ["RTX_AMD_BOX_CULLS"] = "0"
             step()
             sync()
             t1 = time.perf_counter()
             step()
             sync()
-            exact_ms = (time.perf_counter() - t1) * 1e3
+            lean_ms = (time.perf_counter() - t1) * 1e3
             del os.environ["RTX_AMD_BOX_CULLS"]
-            res_exact = ra.film_resolve(film, cam)
-            out["exact_mode"] = {"switch": "RTX_AMD_BOX_CULLS=1", "ms_per_step": exact_ms, "steps": 1}
+            res_lean = ra.film_resolve(film, cam)
+            out["without_box_cull_checks"] = {"switch": "RTX_AMD_BOX_CULLS=0", "ms_per_step": lean_ms, "steps": 1}
             out["cpu_baseline"], cpu_img = cpu_baseline(sd, cam, a)
             if a.cpu_spp in (0, a.spp):   # equal spp: the same samples on both sides
-                out["rmse_vs_cpu"] = rmse_vs_cpu(cpu_img, res_exact["linear"], res["linear"], W, H, a)
+                out["rmse_vs_cpu"] = rmse_vs_cpu(cpu_img, res["linear"], res_lean["linear"], W, H, a)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -326,7 +327,7 @@ class Measured:
         return dict(k, source=self.limiter_src) if k else None
 
 
-def rmse_vs_cpu(cpu_img, gpu_exact, gpu_default, W, H, a):
+def rmse_vs_cpu(cpu_img, gpu_default, gpu_lean, W, H, a):
     """The GPU film against the CPU render of the cpu_baseline leg, on the pixels both hold completely: the 14 x 14 interior
     pixels of the sampled 16 x 16 buckets (tent filter, radius 1: an interior pixel receives samples of its own bucket only)."""
     import numpy as np
@@ -342,9 +343,9 @@ def rmse_vs_cpu(cpu_img, gpu_exact, gpu_default, W, H, a):
         return float(np.sqrt((d * d).mean()) / max(mean_lum, 1e-30))
 
     return {"pixels": int(m.sum()), "spp": a.cpu_spp if a.cpu_spp > 0 else a.spp, "mean_luminance": mean_lum,
-            "rmse_over_mean_exact_mode": rel(gpu_exact), "rmse_over_mean_default": rel(gpu_default), "bar": 1e-5,
-            "note": "per-sample radiance is bit-identical in exact mode; the films differ by the order of their float sums. The default "
-                    "(lean kernels) omits the reference's box culls: about 2 samples in 10^7 end differently (DESIGN.md 4 item 8)"}
+            "rmse_over_mean": rel(gpu_default), "bar": 1e-5, "rmse_over_mean_without_box_cull_checks": rel(gpu_lean),
+            "note": "per-sample radiance is bit-identical to the CPU render; the films differ by the order of their float sums. Without "
+                    "the box-cull checks (RTX_AMD_BOX_CULLS=0) about 2 samples in 10^7 end differently (DESIGN.md 4 item 8)"}
 
 
 def cpu_baseline(sd, cam, a):

@@ -365,10 +365,21 @@ int64_t rtx_refine_list(const rtx_pixel_stats* stats, int width, int height, flo
  * caller-owned DEVICE buffers: out_pixels_dev[0 .. min(count, capacity)) and *out_count_dev = count. The scratch of
  * the ordered compaction is a static device array inside the library (about 256 KB per GPU, held until the process
  * ends), which bounds the frame: width*height above RTX_REFINE_NOALLOC_MAX_PIXELS is refused with RTX_ERR_TOO_LARGE.
- * All calls on one GPU share that array: calls that overlap on one GPU race (serialise them on one stream). */
+ * All calls on one GPU share that array: calls that overlap on one GPU race (serialise them on one stream).
+ * The first call on a device looks the array's address up (hipGetSymbolAddress, which may load the library's code object):
+ * make one call per device outside any graph capture before capturing it. */
 #define RTX_REFINE_NOALLOC_MAX_PIXELS (1ull << 26)
 int rtx_refine_list_noalloc(const rtx_pixel_stats* stats, int width, int height, float ci_halfwidth, int spp_max,
                             int* out_pixels_dev, size_t capacity, uint32_t* out_count_dev, void* stream);
+
+/* The library runs on its own HIP runtime: a host that enqueues rtx_* work asynchronously - the entry point
+ * above, rtx_film_clear with a stream - waits for it with these, not with another runtime's synchronisation (torch's sees
+ * only torch's streams). rtx_device_synchronize: everything enqueued on the current device. rtx_stream_*: a stream of the
+ * library's runtime, usable wherever an rtx_* entry point takes `void* stream`. No counterpart in the reference. */
+int rtx_device_synchronize(void);
+int rtx_stream_create(void** out_stream);
+int rtx_stream_synchronize(void* stream);
+int rtx_stream_destroy(void* stream);
 
 /* Replaces: RayCaster::Stop (RayCaster.cpp:1316-1318): asks an in-flight rtx_render* call on this scene (running in
  * another thread) to stop after the current bounce; that call returns RTX_OK with the samples accumulated so far.

@@ -8,8 +8,25 @@
 #pragma once
 // powf / expf / sinf / cosf / tanf / asinf / acosf / atan2f: the routines the kernels evaluate too (stand-in for the
 // platform libm the reference calls; see the header). Shared on purpose: identical source, identical results.
-#include "../raytracer_amd/csrc/rtx_math.h"
+//
+// ORC_PLATFORM_LIBM (make LIBM=platform -> liboracle_libm.so): the second leg. The same restatement, but the eight functions
+// are the platform's libm, called the way the reference calls them (std::pow of the Blinn lobe, Shading.cpp:334,340;
+// std::exp in ApplyAbsorption, RayCaster.cpp:281-301; std::sin / std::cos of the lens and light sampling ...), and shares no
+// arithmetic source with the product. Its samples are not the kernels' bit for bit - a last bit in a powf is another path a
+// few bounces on - so it is held to the product at image level: tests/test_libm_leg_*.py.
 #include <cmath>
+#ifdef ORC_PLATFORM_LIBM
+inline float rtx_powf(float x, float y) { return std::pow(x, y); }
+inline float rtx_expf(float x) { return std::exp(x); }
+inline float rtx_sinf(float x) { return std::sin(x); }
+inline float rtx_cosf(float x) { return std::cos(x); }
+inline float rtx_tanf(float x) { return std::tan(x); }
+inline float rtx_asinf(float x) { return std::asin(x); }
+inline float rtx_acosf(float x) { return std::acos(x); }
+inline float rtx_atan2f(float y, float x) { return std::atan2(y, x); }
+#else
+#include "../raytracer_amd/csrc/rtx_math.h"
+#endif
 #include <cstdint>
 #include <algorithm>
 

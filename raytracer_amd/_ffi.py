@@ -158,6 +158,10 @@ SYMBOLS = [
                                    c_int_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(Stats)]),
     ("rtx_refine_list", C.c_int64, [C.POINTER(PixelStats), C.c_int, C.c_int, C.c_float, C.c_int, c_int_p, C.c_size_t]),
     ("rtx_refine_list_noalloc", C.c_int, [C.POINTER(PixelStats), C.c_int, C.c_int, C.c_float, C.c_int, _vp, C.c_size_t, _vp, _vp]),
+    ("rtx_device_synchronize", C.c_int, []),
+    ("rtx_stream_create", C.c_int, [C.POINTER(_vp)]),
+    ("rtx_stream_synchronize", C.c_int, [_vp]),
+    ("rtx_stream_destroy", C.c_int, [_vp]),
     ("rtx_cancel", C.c_int, [_vp]),
     ("rtx_render", C.c_int, [_vp, C.POINTER(Camera), C.POINTER(RenderParams), _vp, _vp, _vp, _vp, _vp,
                              C.POINTER(Stats)]),

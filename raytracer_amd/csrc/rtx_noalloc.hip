@@ -36,6 +36,9 @@ __device__ __forceinline__ uint32_t na_flags(const float4* __restrict__ sum, con
     return f;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__AMDGCN_WAVEFRONT_SIZE)
+static_assert(__AMDGCN_WAVEFRONT_SIZE == 64, "na_block_scan assumes wave64 (gfx950): lane = tid & 63, four waves per block");
+#endif
 // exclusive prefix of `v` over the 256 threads of the block (thread order), total in `total`
 __device__ __forceinline__ uint32_t na_block_scan(uint32_t v, uint32_t* waveSums, uint32_t& total) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -139,5 +142,30 @@ extern "C" int rtx_refine_list_noalloc(const rtx_pixel_stats* st, int width, int
     hipLaunchKernelGGL(na_scatter_kernel, dim3(nBlocks), dim3(256), 0, s, sum, sum2, (uint32_t)n, ci_halfwidth, spp_max,
                        (const uint32_t*)ptr, out_pixels_dev, cap);
     RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+extern "C" int rtx_device_synchronize(void) {
+    if (rtx_device_count() <= 0) return rtx_fail(RTX_ERR_NO_DEVICE, "no HIP device present");
+    RTX_HIP(hipDeviceSynchronize());
+    return RTX_OK;
+}
+extern "C" int rtx_stream_create(void** out_stream) {
+    if (!out_stream) return rtx_fail(RTX_ERR_INVALID, "out_stream is NULL");
+    *out_stream = nullptr;
+    if (rtx_device_count() <= 0) return rtx_fail(RTX_ERR_NO_DEVICE, "no HIP device present");
+    hipStream_t s = nullptr;
+    RTX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out_stream = (void*)s;
+    return RTX_OK;
+}
+extern "C" int rtx_stream_synchronize(void* stream) {
+    if (rtx_device_count() <= 0) return rtx_fail(RTX_ERR_NO_DEVICE, "no HIP device present");
+    RTX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return RTX_OK;
+}
+extern "C" int rtx_stream_destroy(void* stream) {
+    if (!stream) return RTX_OK;
+    RTX_HIP(hipStreamDestroy((hipStream_t)stream));
     return RTX_OK;
 }

@@ -390,10 +390,11 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     // Scenes of world-space triangles run the lean kernels, which leave out the reference's root and object box tests
     // (traverse.h ref_box_hit); with `culls` the shade and shadow kernels find the hits those tests would have removed - about
     // 2 in 10^7 samples of the C3 frame - and the general kernels trace them again: the vertex through the tail kernel, the
-    // shadow chain through a second, tiny shadow launch. Opt-in (RTX_AMD_BOX_CULLS=1): the checks cost 4 % of the C3 frame
-    // (shadow 162 -> 194 ms: an object id and a box to fetch at the end of every blocked hop), the general kernels 20 %.
-    bool culls = false;
-    if (const char* e = std::getenv("RTX_AMD_BOX_CULLS")) culls = std::atoi(e) != 0 && !legacy && !s->dev.has_xf && !s->cfg.counting;
+    // shadow chain through a second, tiny shadow launch. On by default since round 3 - every sample of the path loop is then
+    // the oracle's bit for bit - at 4 % of the C3 frame (shadow 162 -> 186 ms: an object id and a box to fetch at the end of
+    // every blocked hop; the general kernels would cost 20 %). RTX_AMD_BOX_CULLS=0 switches the checks off.
+    bool culls = !legacy && !s->dev.has_xf && !s->cfg.counting;
+    if (const char* e = std::getenv("RTX_AMD_BOX_CULLS")) culls = culls && std::atoi(e) != 0;
     if (!culls) pool.cullPaths = pool.cullShadows = nullptr;
     DevScene devGeneral = s->dev;
     if (culls) devGeneral.has_xf = 1;   // tail kernel and re-traces: the instantiation that repeats the box tests

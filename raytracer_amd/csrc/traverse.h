@@ -105,10 +105,14 @@ __device__ __forceinline__ bool well_inside_box(const float* box, float px, floa
 }
 // (out of line for the shadow kernel, whose loop then keeps its registers: 221 -> 191 ms per C3 frame; a call inside the
 // shade kernel costs it 100 ms instead; reached for hits near a box face only)
-__device__ __noinline__ bool ref_reaches_exact(const float* rootBox, const float* objBox, float ox, float oy, float oz, float dx, float dy, float dz,
-                                               float tmax) {
-    if (!ref_box_hit(rootBox, ox, oy, oz, dx, dy, dz, tmax)) return false;
-    return ref_box_hit(objBox, ox, oy, oz, dx, dy, dz, tmax);
+// (the boxes by value: a pointer into the kernel's scene argument would make the compiler keep a copy of the whole descriptor in
+// scratch memory for the sake of this one call)
+struct Box6 {
+    float v[6];
+};
+__device__ __noinline__ bool ref_reaches_exact(Box6 rootBox, Box6 objBox, float ox, float oy, float oz, float dx, float dy, float dz, float tmax) {
+    if (!ref_box_hit(rootBox.v, ox, oy, oz, dx, dy, dz, tmax)) return false;
+    return ref_box_hit(objBox.v, ox, oy, oz, dx, dy, dz, tmax);
 }
 // Does the reference reach triangle `slot` of a scene of world-space triangles with ray r, which hits it at t? (the
 // root's box, then the object's own: IntersectNodeAdapter.h:30-32, :63-75). The exact tests run only for hits near a
@@ -118,7 +122,15 @@ __device__ __forceinline__ bool ref_reaches_box(const DevScene& sc, const RayT& 
     const float px = r.ox + r.dx * t, py = r.oy + r.dy * t, pz = r.oz + r.dz * t;
     const bool sure = t < 1e6f && r.tmax > t * 1.001f && well_inside_box(sc.bounds, px, py, pz, t) && well_inside_box(obox, px, py, pz, t);
     if (sure) return true;
-    if (OUTLINE) return ref_reaches_exact(sc.bounds, obox, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.tmax);
+    if (OUTLINE) {
+        Box6 rb, ob;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            rb.v[i] = sc.bounds[i];
+            ob.v[i] = obox[i];
+        }
+        return ref_reaches_exact(rb, ob, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.tmax);
+    }
     if (!ref_box_hit(sc.bounds, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.tmax)) return false;
     return ref_box_hit(obox, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.tmax);
 }

@@ -10,16 +10,30 @@ from raytracer_amd import _ffi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # ORACLE_LIB selects another build of the oracle (A/B runs of experimental variants)
 LIB = os.environ.get("ORACLE_LIB") or os.path.join(ROOT, "oracle", "liboracle.so")
+# the leg whose elementary functions are the platform libm (oracle/oracle_math.h, ORC_PLATFORM_LIBM)
+LIB_LIBM = os.path.join(ROOT, "oracle", "liboracle_libm.so")
 _lib = None
+_lib_libm = None
 _vp = C.c_void_p
 
 
-def lib():
-    global _lib
+def lib(libm=False):
+    """The oracle library; libm=True: the build that calls the platform libm instead of the routines shared with the kernels."""
+    global _lib, _lib_libm
+    if libm:
+        if _lib_libm is None:
+            _lib_libm = _load(LIB_LIBM)
+        return _lib_libm
     if _lib is None:
-        if not os.path.exists(LIB):
+        _lib = _load(LIB)
+    return _lib
+
+
+def _load(path):
+    if True:
+        if not os.path.exists(path):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
-        L = C.CDLL(LIB)
+        L = C.CDLL(path)
         L.orc_halton.restype = C.c_float
         L.orc_halton.argtypes = [C.c_int, C.c_int]
         L.orc_rnd.restype = C.c_float
@@ -30,13 +44,12 @@ def lib():
         L.orc_photon_download.argtypes = [_vp, C.c_int, _vp, C.c_size_t]
         L.orc_scene_destroy.argtypes = [_vp]
         L.orc_photon_destroy.argtypes = [_vp]
-        _lib = L
-    return _lib
+    return L
 
 
 class OracleScene:
-    def __init__(self, data):
-        self.L = lib()
+    def __init__(self, data, libm=False):
+        self.L = lib(libm)
         self.data = data
         desc, self._keep = data.to_desc()
         h = _vp()

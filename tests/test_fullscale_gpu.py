@@ -144,8 +144,9 @@ def test_full_size_path_samples_against_oracle(full, full_oracle):
 def test_reference_box_culls_full_size(full, full_oracle, monkeypatch):
     """The lean kernels (scenes of world-space triangles) leave out the reference's root and object box tests
     (scene_box.cpp:8-46 through IntersectNodeAdapter.h:30-32, :63-75), which cull a hit within rounding of a box face:
-    about 2 camera samples in 10^7 end differently. RTX_AMD_BOX_CULLS=1 finds those hits after the fact and traces them
-    again with the general kernels: the samples that change are then the oracle's bit for bit, and so is every other."""
+    about 2 camera samples in 10^7 end differently. The path loop finds those hits after the fact and traces them again
+    with the general kernels (the default since round 3; RTX_AMD_BOX_CULLS=0 switches the checks off): the samples that
+    change are then the oracle's bit for bit, and so is every other."""
     sd, gs, cam = full
     spp = 4
     rp = render_params(spp_min=spp, max_bounces=64)
@@ -154,6 +155,8 @@ def test_reference_box_culls_full_size(full, full_oracle, monkeypatch):
     monkeypatch.setenv("RTX_AMD_BOX_CULLS", "1")
     exact, st1 = gs.render_samples(cam, rp)
     monkeypatch.delenv("RTX_AMD_BOX_CULLS")
+    default, _ = gs.render_samples(cam, rp)
+    assert np.array_equal(default.view(np.uint32), exact.view(np.uint32))   # the checks are on unless switched off
     diff = (lean.view(np.uint32) != exact.view(np.uint32)).any(-1)          # [H, W, spp]
     assert 0 < diff.sum() < 100, diff.sum()                                 # measured: 2 of 8.3 M
     ys, xs, ss = np.nonzero(diff)
@@ -165,6 +168,6 @@ def test_reference_box_culls_full_size(full, full_oracle, monkeypatch):
     from tests.helpers import assert_path_samples_identical
     assert_path_samples_identical(exact[xys[:, 1], xys[:, 0], xys[:, 2]], o)
     n = len(xs)
-    assert (lean[ys, xs, ss].view(np.uint32) != o[:n].view(np.uint32)).any(-1).all()   # the default kernels differ from the oracle exactly there
+    assert (lean[ys, xs, ss].view(np.uint32) != o[:n].view(np.uint32)).any(-1).all()   # without the checks the kernels differ from the oracle exactly there
     for key in ("rays_primary", "paths"):
         assert st0[key] == st1[key]

@@ -29,19 +29,20 @@ def _random_stats(torch, W, H, spp_max, seed):
     return torch.from_numpy(s1).to(dev), torch.from_numpy(s2).to(dev)
 
 
-def _both(torch, W, H, spp_max, ci, seed, capacity=None):
+def _both(torch, W, H, spp_max, ci, seed, capacity=None, stream=None):
     s1, s2 = _random_stats(torch, W, H, spp_max, seed)
     pst = _ffi.PixelStats(s1.data_ptr(), s2.data_ptr())
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()            # torch has filled the inputs (its own runtime: a host wait is the only ordering there is)
     want = api.refine_list(pst, W, H, ci, spp_max)
     cap = W * H if capacity is None else capacity
     out = torch.full((max(cap, 1),), -7, dtype=torch.int32, device=s1.device)
     cnt = torch.zeros(1, dtype=torch.int32, device=s1.device)
     torch.cuda.synchronize()
-    api.refine_list_noalloc(pst, W, H, ci, spp_max, out.data_ptr(), cap, cnt.data_ptr(), None)
+    api.refine_list_noalloc(pst, W, H, ci, spp_max, out.data_ptr(), cap, cnt.data_ptr(), stream)
     lib = _ffi.load_library()
-    # the entry point synchronises nothing: the caller does (null stream here)
-    torch.cuda.synchronize()
+    # The entry point synchronises nothing: the caller does - with the LIBRARY's runtime, on which the kernels were enqueued
+    # (torch.cuda.synchronize() waits for torch's own runtime only).
+    assert (lib.rtx_stream_synchronize(stream) if stream else lib.rtx_device_synchronize()) == 0, lib.rtx_last_error()
     return want, out.cpu().numpy(), int(cnt.item())
 
 
@@ -61,6 +62,16 @@ def test_noalloc_matches_refine_list_twice_in_a_row(rtx):
     # nothing to refine
     want4, got4, cnt4 = _both(torch, 64, 64, 2, 0.5, seed=3)
     assert len(want4) == 0 and cnt4 == 0 and (got4 == -7).all()
+    # on a stream of the library's runtime instead of the null stream, twice (the shared scratch is reused in stream order)
+    lib = _ffi.load_library()
+    st = C.c_void_p()
+    assert lib.rtx_stream_create(C.byref(st)) == 0, lib.rtx_last_error()
+    try:
+        for seed, (W, H) in ((4, (640, 360)), (5, (257, 129))):
+            w5, g5, c5 = _both(torch, W, H, 48, 0.015, seed=seed, stream=st)
+            assert 0 < len(w5) and c5 == len(w5) and np.array_equal(g5[:c5], w5) and (g5[c5:] == -7).all()
+    finally:
+        assert lib.rtx_stream_destroy(st) == 0
 
 
 def test_noalloc_rejects_oversize_and_bad_arguments(rtx):
