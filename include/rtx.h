@@ -480,6 +480,12 @@ int rtx_get_counters(rtx_scene* scene, uint64_t out[3]);
  * `producer_blocks` blocks of `block_threads` threads appending at most `mult` entries per thread: start[s] = first
  * item index of segment s (64 segments), segment_of_block[b] for every block (array of producer_blocks). */
 int rtx_debug_validate_bvh(const rtx_scene_desc* desc, uint64_t out[3]);
+/* A host model of the kernels' traversal order (no device needed): flattens desc, walks n rays {o, tmax, d} to their closest
+ * hit among the world-space triangles in the order the kernels visit the tree, and returns t_out[i] (-1 = miss), prim_out[i]
+ * (global triangle id, -1 = miss), counts[0] = nodes visited, [1] = triangles tested, [2] = nodes of the tree, [3] = depth.
+ * The CPU tests hold it to a brute-force loop (the tree loses no hit), and it prices a change of the tree layout in steps
+ * per ray before any kernel is written. Not a render path. */
+int rtx_debug_host_walk(const rtx_scene_desc* desc, const rtx_ray* rays, size_t n, float* t_out, int* prim_out, uint64_t counts[4]);
 /* The elementary functions of the path as this library evaluates them (raytracer_amd/csrc/rtx_math.h; the reference calls
  * the platform libm): fn 0 powf(x, y), 1 expf(x), 2 sinf, 3 cosf, 4 tanf, 5 asinf, 6 acosf, 7 atan2f(x, y), 8 x / 255 for
  * x = 0 ... 255 (the texel conversion, which must equal the IEEE division); host arrays

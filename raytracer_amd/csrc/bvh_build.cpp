@@ -245,6 +245,7 @@ struct Emitter {
         out.attrs.push_back(a);
     }
 
+#if !RTX_BVH8
     uint32_t emit(int id, int depth) {
         const N2& n = B.nodes[id];
         maxDepth = std::max(maxDepth, depth);
@@ -352,6 +353,174 @@ struct Emitter {
         out.nodes[my] = nd;
         return my;
     }
+#else
+    // ---- 8-wide form (layout.h Node8) ----
+    // Quantised planes of up to 8 child boxes along axis a of a node whose box starts at o: the smallest power-of-two step
+    // (not below 2^-40 of the node's largest step, Efloor) with which every child's upper plane fits in 8 bits.
+    bool quantise_axis(float o, float extent, int Efloor, const AABB* const cb[8], int a, uint8_t qlo[8], uint8_t qhi[8], uint8_t& Eout) {
+        int E = 1;
+        if (extent > 0.0f) {
+            int e;
+            std::frexp(extent / 255.0f, &e);  // extent/255 = m * 2^e, m in [0.5,1)
+            E = e + 127;
+        }
+        if (E < Efloor) E = Efloor;
+        for (;; ++E) {
+            if (E > 253) {  // the kernels also need 2^-E (biased exponent 254-E) as a normal float
+                err = "scene extent too large to quantise";
+                return false;
+            }
+            uint32_t bits = (uint32_t)E << 23;
+            float scale;
+            std::memcpy(&scale, &bits, 4);
+            bool ok = true;
+            for (int i = 0; i < 8; ++i) {
+                if (!cb[i]) {
+                    qlo[i] = 255;  // inverted box (and the slot is not in the node's valid mask)
+                    qhi[i] = 0;
+                    continue;
+                }
+                int ql = (int)std::floor(((double)cb[i]->lo[a] - (double)o) / (double)scale);
+                ql = std::min(255, std::max(0, ql));
+                while (ql > 0 && decode_q(o, ql, scale) > cb[i]->lo[a]) --ql;
+                int qh = (int)std::ceil(((double)cb[i]->hi[a] - (double)o) / (double)scale);
+                qh = std::max(0, qh);
+                while (qh <= 255 && decode_q(o, qh, scale) < cb[i]->hi[a]) ++qh;
+                if (qh > 255) {
+                    ok = false;
+                    break;
+                }
+                qlo[i] = (uint8_t)ql;
+                qhi[i] = (uint8_t)qh;
+            }
+            if (ok) break;
+        }
+        Eout = (uint8_t)E;
+        return true;
+    }
+
+    // Fills node `my` from the binary subtree `id`; returns whether the subtree holds a surface that lets light through.
+    bool fill8(uint32_t my, int id, int depth) {
+        static_assert(RTX_MAX_LEAF <= RTX_LEAF8_MAX, "Node8 masks hold 3 triangles per leaf child");
+        const N2& n = B.nodes[id];
+        maxDepth = std::max(maxDepth, depth);
+        // collapse: open the inner child with the largest surface area until there are 8 children
+        int c[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+        int nc;
+        if (n.count > 0) {   // the whole scene is one leaf
+            c[0] = id;
+            nc = 1;
+        } else {
+            c[0] = n.left;
+            c[1] = n.right;
+            nc = 2;
+            while (nc < 8) {
+                int best = -1;
+                float bestA = -1.0f;
+                for (int i = 0; i < nc; ++i) {
+                    const N2& ch = B.nodes[c[i]];
+                    if (ch.count > 0) continue;
+                    float a = ch.box.area();
+                    if (a > bestA) {
+                        bestA = a;
+                        best = i;
+                    }
+                }
+                if (best < 0) break;
+                int l = B.nodes[c[best]].left, r = B.nodes[c[best]].right;
+                c[best] = l;
+                c[nc++] = r;
+            }
+        }
+        // slots: child towards corner s of the node (bit a of s set = high side on axis a) goes to slot s, greedily by
+        // the projection of (child centre - node centre) on the corner's diagonal; the traversal visits slots in the order
+        // of "slot XOR ray octant", which is then roughly front to back
+        int slotChild[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+        {
+            float pc[3];
+            for (int a = 0; a < 3; ++a) pc[a] = 0.5f * (n.box.lo[a] + n.box.hi[a]);
+            float cost[8][8];
+            for (int i = 0; i < nc; ++i) {
+                const AABB& b = B.nodes[c[i]].box;
+                float d[3];
+                for (int a = 0; a < 3; ++a) d[a] = 0.5f * (b.lo[a] + b.hi[a]) - pc[a];
+                for (int sl = 0; sl < 8; ++sl) cost[i][sl] = ((sl & 1) ? d[0] : -d[0]) + ((sl & 2) ? d[1] : -d[1]) + ((sl & 4) ? d[2] : -d[2]);
+            }
+            bool cUsed[8] = {false}, sUsed[8] = {false};
+            for (int k = 0; k < nc; ++k) {
+                int bi = -1, bs = -1;
+                float bv = -1e30f;
+                for (int i = 0; i < nc; ++i) {
+                    if (cUsed[i]) continue;
+                    for (int sl = 0; sl < 8; ++sl)
+                        if (!sUsed[sl] && cost[i][sl] > bv) {
+                            bv = cost[i][sl];
+                            bi = i;
+                            bs = sl;
+                        }
+                }
+                cUsed[bi] = true;
+                sUsed[bs] = true;
+                slotChild[bs] = c[bi];
+            }
+        }
+        Node8 nd;
+        std::memset(&nd, 0, sizeof(nd));
+        nd.ox = n.box.lo[0]; nd.oy = n.box.lo[1]; nd.oz = n.box.lo[2];
+        uint32_t valid = 0, imask = 0, tvalid = 0, ttrans = 0, tmask = 0;
+        nd.triBase = (uint32_t)out.tris.size();
+        const AABB* cb[8];
+        for (int sl = 0; sl < 8; ++sl) {
+            cb[sl] = nullptr;
+            if (slotChild[sl] < 0) continue;
+            const N2& cn = B.nodes[slotChild[sl]];
+            cb[sl] = &cn.box;
+            valid |= 1u << sl;
+            if (cn.count == 0) {
+                imask |= 1u << sl;
+                continue;
+            }
+            for (int j = 0; j < cn.count; ++j) {
+                const size_t rec = out.tris.size();
+                emit_tri(B.idx[cn.first + j]);
+                tvalid |= 1u << (3 * sl + j);
+                if ((out.tris[rec].obj & TRI_OPAQUE) == 0u) {
+                    ttrans |= 1u << (3 * sl + j);
+                    tmask |= 1u << sl;
+                }
+            }
+        }
+        int kInner = 0;
+        for (int sl = 0; sl < 8; ++sl) kInner += (imask >> sl) & 1u;
+        const uint32_t childBase = kInner ? (uint32_t)out.nodes.size() : 0u;
+        if (kInner) out.nodes.resize(out.nodes.size() + (size_t)kInner);
+        nd.childBase = childBase;
+        nd.imask = (uint8_t)imask;
+        int Efloor = 30;
+        for (int a = 0; a < 3; ++a) {
+            float extent = n.box.hi[a] - n.box.lo[a];
+            if (extent > 0.0f) {
+                int e;
+                std::frexp(extent / 255.0f, &e);
+                Efloor = std::max(Efloor, e + 127 - 40);
+            }
+        }
+        const float o[3] = {nd.ox, nd.oy, nd.oz};
+        uint8_t* ebytes[3] = {&nd.ex, &nd.ey, &nd.ez};
+        for (int a = 0; a < 3; ++a)
+            if (!quantise_axis(o[a], n.box.hi[a] - n.box.lo[a], Efloor, cb, a, nd.qlo[a], nd.qhi[a], *ebytes[a])) return false;
+        int ord = 0;
+        for (int sl = 0; sl < 8; ++sl) {
+            if (!((imask >> sl) & 1u)) continue;
+            if (fill8(childBase + (uint32_t)ord, slotChild[sl], depth + 1)) tmask |= 1u << sl;
+            ++ord;
+        }
+        nd.tvalid = tvalid | (tmask << 24);
+        nd.ttrans = ttrans | (valid << 24);
+        out.nodes[my] = nd;
+        return tmask != 0u;
+    }
+#endif
 };
 
 }  // namespace
@@ -555,6 +724,17 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
     out.attrs.reserve(total);
     out.nodes.reserve(total / 2 + 16);
     Emitter E{B, src, desc, faceBase, out};
+#if RTX_BVH8
+    out.nodes.resize(1);
+    E.fill8(0u, root, 0);
+    out.root = 0u;   // always a node (a scene of one or two triangles: a root with one leaf child)
+    out.depth = E.maxDepth;
+    if (!E.err.empty()) {
+        err = E.err;
+        return false;
+    }
+    return true;
+#else
     out.root = E.emit(root, 0);
     out.depth = E.maxDepth;
     if (!E.err.empty()) {
@@ -578,6 +758,7 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
         if (trans) out.root |= 0x40000000u;
     }
     return true;
+#endif
 }
 
 namespace {
@@ -585,6 +766,102 @@ struct Validator {
     const HostScene& hs;
     std::vector<uint8_t> seen;
     std::string err;
+    // exact box of triangle record i, marked as seen
+    AABB tri_box(uint32_t i) {
+        AABB b;
+        if (i >= hs.tris.size()) {
+            err = "leaf range out of bounds";
+            return b;
+        }
+        if (seen[i]++) err = "triangle referenced twice";
+        const TriRec& t = hs.tris[i];
+        float v0[3] = {t.v0x, t.v0y, t.v0z};
+        float v1[3] = {t.v0x + t.e1x, t.v0y + t.e1y, t.v0z + t.e1z};
+        float v2[3] = {t.v0x + t.e2x, t.v0y + t.e2y, t.v0z + t.e2z};
+        if (t.kind == RTX_KIND_XFTRI) {   // object-space record: its box is the world-space one
+            const float* F = hs.objXf[t.obj & TRI_OBJ_MASK].fwd;
+            float w0[3], w1[3], w2[3];
+            xf_point(F, v0, w0);
+            xf_point(F, v1, w1);
+            xf_point(F, v2, w2);
+            b.add(w0);
+            b.add(w1);
+            b.add(w2);
+        } else {
+            b.add(v0);
+            b.add(v1);
+            b.add(v2);
+        }
+        return b;
+    }
+    // is the exact box cb inside the quantised box (o, e, qlo, qhi) of a child? (v1/v2 are re-derived as v0+e, one rounding each)
+    bool contains(const float o[3], const uint8_t e[3], const uint8_t qlo[3], const uint8_t qhi[3], const AABB& cb) {
+        for (int a = 0; a < 3; ++a) {
+            uint32_t bits = (uint32_t)e[a] << 23;
+            float scale;
+            std::memcpy(&scale, &bits, 4);
+            double lo = decode_q(o[a], qlo[a], scale), hi = decode_q(o[a], qhi[a], scale);
+            float slack = 4e-7f * std::max(std::fabs(cb.lo[a]), std::fabs(cb.hi[a])) + 1e-30f;
+            if (lo > cb.lo[a] + slack || hi < cb.hi[a] - slack) return false;
+        }
+        return true;
+    }
+#if RTX_BVH8
+    // returns the exact box of the subtree of node `ref`; trans: whether it holds a surface that lets light through
+    AABB walk(uint32_t ref, bool* transOut = nullptr) {
+        AABB b;
+        if (ref >= hs.nodes.size()) {
+            err = "node index out of bounds";
+            return b;
+        }
+        const Node8& n = hs.nodes[ref];
+        const float o[3] = {n.ox, n.oy, n.oz};
+        const uint8_t e[3] = {n.ex, n.ey, n.ez};
+        const uint32_t valid = n.ttrans >> 24, tmask = n.tvalid >> 24, tvalid = n.tvalid & 0xFFFFFFu, ttrans = n.ttrans & 0xFFFFFFu;
+        uint32_t ord = 0, tri = n.triBase;
+        bool any = false;
+        if (ttrans & ~tvalid) err = "transmissive bit without a triangle";
+        for (int sl = 0; sl < 8; ++sl) {
+            const bool inner = (n.imask >> sl) & 1u;
+            const uint32_t tb = (tvalid >> (3 * sl)) & 7u;
+            if (!((valid >> sl) & 1u)) {
+                if (inner || tb) err = "child in a slot that is not marked valid";
+                continue;
+            }
+            AABB cb;
+            bool trans = false;
+            if (inner) {
+                if (tb) err = "slot is both inner and leaf";
+                cb = walk(n.childBase + ord++, &trans);
+            } else {
+                if (tb != 1u && tb != 3u && tb != 7u) err = "leaf triangle bits are not a prefix";
+                for (int j = 0; j < 3; ++j)
+                    if ((tb >> j) & 1u) {
+                        if (tri < hs.tris.size() && (hs.tris[tri].obj & TRI_OPAQUE) == 0u) {
+                            trans = true;
+                            if (!((ttrans >> (3 * sl + j)) & 1u)) err = "transmissive triangle not flagged";
+                        } else if ((ttrans >> (3 * sl + j)) & 1u)
+                            err = "opaque triangle flagged transmissive";
+                        cb.add(tri_box(tri++));
+                    }
+            }
+            if (!err.empty()) return b;
+            if (trans != (((tmask >> sl) & 1u) != 0u)) {
+                err = "transmissive-subtree mask is wrong";
+                return b;
+            }
+            any = any || trans;
+            const uint8_t ql[3] = {n.qlo[0][sl], n.qlo[1][sl], n.qlo[2][sl]}, qh[3] = {n.qhi[0][sl], n.qhi[1][sl], n.qhi[2][sl]};
+            if (!contains(o, e, ql, qh, cb)) {
+                err = "quantised child box does not contain its subtree";
+                return b;
+            }
+            b.add(cb);
+        }
+        if (transOut) *transOut = any;
+        return b;
+    }
+#else
     // returns the exact box of the subtree
     AABB walk(uint32_t ref) {
         AABB b;
@@ -592,29 +869,8 @@ struct Validator {
         if (ref & RTX_LEAF_FLAG) {
             uint32_t first = (ref & 0x7FFFFFFFu) >> 3, cnt = (ref & 7u) + 1;
             for (uint32_t i = first; i < first + cnt; ++i) {
-                if (i >= hs.tris.size()) {
-                    err = "leaf range out of bounds";
-                    return b;
-                }
-                if (seen[i]++) err = "triangle referenced twice";
-                const TriRec& t = hs.tris[i];
-                float v0[3] = {t.v0x, t.v0y, t.v0z};
-                float v1[3] = {t.v0x + t.e1x, t.v0y + t.e1y, t.v0z + t.e1z};
-                float v2[3] = {t.v0x + t.e2x, t.v0y + t.e2y, t.v0z + t.e2z};
-                if (t.kind == RTX_KIND_XFTRI) {   // object-space record: its box is the world-space one
-                    const float* F = hs.objXf[t.obj & TRI_OBJ_MASK].fwd;
-                    float w0[3], w1[3], w2[3];
-                    xf_point(F, v0, w0);
-                    xf_point(F, v1, w1);
-                    xf_point(F, v2, w2);
-                    b.add(w0);
-                    b.add(w1);
-                    b.add(w2);
-                } else {
-                    b.add(v0);
-                    b.add(v1);
-                    b.add(v2);
-                }
+                b.add(tri_box(i));
+                if (!err.empty()) return b;
             }
             return b;
         }
@@ -629,22 +885,16 @@ struct Validator {
             if (n.child[i] == RTX_EMPTY_CHILD) continue;
             AABB cb = walk(n.child[i]);
             if (!err.empty()) return b;
-            for (int a = 0; a < 3; ++a) {
-                uint32_t bits = (uint32_t)e[a] << 23;
-                float scale;
-                std::memcpy(&scale, &bits, 4);
-                double lo = decode_q(o[a], n.qlo[a][i], scale), hi = decode_q(o[a], n.qhi[a][i], scale);
-                // v1/v2 are re-derived as v0+e (one rounding each), allow that slack
-                float slack = 4e-7f * std::max(std::fabs(cb.lo[a]), std::fabs(cb.hi[a])) + 1e-30f;
-                if (lo > cb.lo[a] + slack || hi < cb.hi[a] - slack) {
-                    err = "quantised child box does not contain its subtree";
-                    return b;
-                }
+            const uint8_t ql[3] = {n.qlo[0][i], n.qlo[1][i], n.qlo[2][i]}, qh[3] = {n.qhi[0][i], n.qhi[1][i], n.qhi[2][i]};
+            if (!contains(o, e, ql, qh, cb)) {
+                err = "quantised child box does not contain its subtree";
+                return b;
             }
             b.add(cb);
         }
         return b;
     }
+#endif
 };
 }  // namespace
 
@@ -657,4 +907,219 @@ std::string validate_host_scene(const HostScene& hs) {
     for (size_t i = 0; i < v.seen.size(); ++i)
         if (v.seen[i] != 1) return "triangle not referenced exactly once";
     return "";
+}
+
+// ---- a host model of the kernels' traversal order (rtx_debug_host_walk): which nodes a ray visits and which triangles it
+// tests, in the order of traverse.h, in plain C++ on decoded boxes. For the CPU tests of the tree and for counting steps when
+// a tree layout is changed; no product path calls it.
+namespace {
+struct WalkRay {
+    float o[3], d[3], id[3], tmax;
+};
+// slab test against the box {lo, hi}; returns entry distance or a negative number for a miss
+inline float walk_slab(const WalkRay& r, const float lo[3], const float hi[3], float best) {
+    float tn = 0.0f, tf = best;
+    for (int a = 0; a < 3; ++a) {
+        float t0 = (lo[a] - r.o[a]) * r.id[a], t1 = (hi[a] - r.o[a]) * r.id[a];
+        if (r.id[a] < 0.0f || (r.id[a] == 0.0f && std::signbit(r.id[a]))) std::swap(t0, t1);
+        if (t0 == t0) tn = std::max(tn, t0);
+        if (t1 == t1) tf = std::min(tf, t1);
+    }
+    return tn <= tf * 1.00001f ? tn : -1.0f;
+}
+inline void walk_tri(const HostScene& hs, uint32_t slot, const WalkRay& r, float& best, int& bestSlot, uint32_t& bestPrim) {
+    const TriRec& T = hs.tris[slot];
+    if (T.kind != 0u) return;   // world-space triangles only (the model is for step counts and tree checks)
+    const float px = r.d[1] * T.e2z - r.d[2] * T.e2y, py = r.d[2] * T.e2x - r.d[0] * T.e2z, pz = r.d[0] * T.e2y - r.d[1] * T.e2x;
+    const float det = T.e1x * px + T.e1y * py + T.e1z * pz;
+    if (std::fabs(det) < 1e-7f) return;
+    const float inv = 1.0f / det;
+    const float tx = r.o[0] - T.v0x, ty = r.o[1] - T.v0y, tz = r.o[2] - T.v0z;
+    const float u = (tx * px + ty * py + tz * pz) * inv;
+    if (u < 0.0f || u > 1.0f) return;
+    const float qx = ty * T.e1z - tz * T.e1y, qy = tz * T.e1x - tx * T.e1z, qz = tx * T.e1y - ty * T.e1x;
+    const float v = (r.d[0] * qx + r.d[1] * qy + r.d[2] * qz) * inv;
+    if (v < 0.0f || u + v > 1.0f) return;
+    const float t = (T.e2x * qx + T.e2y * qy + T.e2z * qz) * inv;
+    if (t <= 1e-7f) return;
+    if (t > best || (t == best && (bestSlot < 0 || T.prim >= bestPrim))) return;
+    best = t;
+    bestSlot = (int)slot;
+    bestPrim = T.prim;
+}
+inline float walk_scale(uint8_t e) {
+    uint32_t bits = (uint32_t)e << 23;
+    float sc;
+    std::memcpy(&sc, &bits, 4);
+    return sc;
+}
+}  // namespace
+
+void host_walk_closest(const HostScene& hs, const float* ray8, float* tOut, int* primOut, uint64_t counts[2]) {
+    WalkRay r;
+    for (int a = 0; a < 3; ++a) {
+        r.o[a] = ray8[a];
+        r.d[a] = ray8[4 + a];
+        r.id[a] = 1.0f / r.d[a];
+    }
+    r.tmax = ray8[3];
+    float best = r.tmax;
+    int bestSlot = -1;
+    uint32_t bestPrim = 0xFFFFFFFFu;
+    uint64_t nNodes = 0, nTris = 0;
+    if (hs.root != RTX_EMPTY_CHILD) {
+#if RTX_BVH8
+        const uint32_t octInv = 7u ^ ((r.id[0] < 0.0f || std::signbit(r.id[0]) ? 1u : 0u) | (r.id[1] < 0.0f || std::signbit(r.id[1]) ? 2u : 0u) |
+                                      (r.id[2] < 0.0f || std::signbit(r.id[2]) ? 4u : 0u));
+        struct Grp {
+            uint32_t base, mask;   // mask: [31:24] hit slots in priority space (priority = slot ^ octInv, highest first), [7:0] imask
+        };
+        std::vector<Grp> stack;
+        Grp G{hs.root, (1u << (24 + (0u ^ octInv))) | 1u};   // the root as a group of one inner child in slot 0
+        static const int ideal = std::getenv("BVH8_IDEAL") ? std::atoi(std::getenv("BVH8_IDEAL")) : 0;
+        if (ideal) {   // experiment: per-child entries with entry distances, nearest first, culled when popped
+            struct Ent { uint32_t node; float t; };
+            std::vector<Ent> st2;
+            st2.push_back(Ent{hs.root, 0.0f});
+            while (!st2.empty()) {
+                const Ent e = st2.back();
+                st2.pop_back();
+                if (!(e.t <= best * 1.00001f)) continue;
+                const Node8& n = hs.nodes[e.node];
+                ++nNodes;
+                const float o[3] = {n.ox, n.oy, n.oz};
+                const float sc[3] = {walk_scale(n.ex), walk_scale(n.ey), walk_scale(n.ez)};
+                const uint32_t valid = n.ttrans >> 24, tvalid = n.tvalid & 0xFFFFFFu;
+                Ent h[8]; int nh = 0; uint32_t ord = 0;
+                struct LT { uint32_t sl; float t; } lf[8]; int nl = 0;
+                for (int sl = 0; sl < 8; ++sl) {
+                    const bool inner = (n.imask >> sl) & 1u;
+                    const uint32_t myOrd = ord;
+                    if (inner) ++ord;
+                    if (!((valid >> sl) & 1u)) continue;
+                    float lo[3], hi[3];
+                    for (int a = 0; a < 3; ++a) {
+                        lo[a] = o[a] + (float)n.qlo[a][sl] * sc[a];
+                        hi[a] = o[a] + (float)n.qhi[a][sl] * sc[a];
+                    }
+                    const float t = walk_slab(r, lo, hi, best);
+                    if (t < 0.0f) continue;
+                    if (inner) h[nh++] = Ent{n.childBase + myOrd, t};
+                    else lf[nl++] = LT{(uint32_t)sl, t};
+                }
+                if (ideal == 2) std::sort(lf, lf + nl, [](const LT& a, const LT& b) { return a.t < b.t; });
+                for (int i = 0; i < nl; ++i) {
+                    if (ideal == 2 && !(lf[i].t <= best * 1.00001f)) continue;
+                    uint32_t tm = (7u << (3 * lf[i].sl)) & tvalid;
+                    while (tm) {
+                        const uint32_t b = (uint32_t)__builtin_ctz(tm);
+                        tm &= tm - 1u;
+                        ++nTris;
+                        walk_tri(hs, n.triBase + (uint32_t)__builtin_popcount(tvalid & ((1u << b) - 1u)), r, best, bestSlot, bestPrim);
+                    }
+                }
+                std::stable_sort(h, h + nh, [](const Ent& a, const Ent& b) { return a.t > b.t; });
+                for (int i = 0; i < nh; ++i) st2.push_back(h[i]);
+            }
+        } else
+        for (;;) {
+            if ((G.mask >> 24) == 0u) {
+                if (stack.empty()) break;
+                G = stack.back();
+                stack.pop_back();
+                continue;
+            }
+            const uint32_t p = 31u - (uint32_t)__builtin_clz(G.mask);
+            G.mask &= ~(1u << p);
+            const uint32_t slot = (p - 24u) ^ octInv;
+            const uint32_t node = G.base + (uint32_t)__builtin_popcount(G.mask & 0xFFu & ((1u << slot) - 1u));
+            if ((G.mask >> 24) != 0u) stack.push_back(G);
+            const Node8& n = hs.nodes[node];
+            ++nNodes;
+            const float o[3] = {n.ox, n.oy, n.oz};
+            const float sc[3] = {walk_scale(n.ex), walk_scale(n.ey), walk_scale(n.ez)};
+            const uint32_t valid = n.ttrans >> 24, tvalid = n.tvalid & 0xFFFFFFu;
+            uint32_t hm = 0;
+            for (int sl = 0; sl < 8; ++sl) {
+                if (!((valid >> sl) & 1u)) continue;
+                float lo[3], hi[3];
+                for (int a = 0; a < 3; ++a) {
+                    lo[a] = o[a] + (float)n.qlo[a][sl] * sc[a];
+                    hi[a] = o[a] + (float)n.qhi[a][sl] * sc[a];
+                }
+                if (walk_slab(r, lo, hi, best) >= 0.0f) hm |= 1u << sl;
+            }
+            // triangles of the leaf children that were hit, in record order
+            uint32_t tm = 0;
+            for (int sl = 0; sl < 8; ++sl)
+                if (((hm & ~(uint32_t)n.imask) >> sl) & 1u) tm |= 7u << (3 * sl);
+            tm &= tvalid;
+            while (tm) {
+                const uint32_t b = (uint32_t)__builtin_ctz(tm);
+                tm &= tm - 1u;
+                ++nTris;
+                walk_tri(hs, n.triBase + (uint32_t)__builtin_popcount(tvalid & ((1u << b) - 1u)), r, best, bestSlot, bestPrim);
+            }
+            uint32_t hi8 = hm & n.imask, P = 0;
+            for (int sl = 0; sl < 8; ++sl)
+                if ((hi8 >> sl) & 1u) P |= 1u << ((uint32_t)sl ^ octInv);
+            G = Grp{n.childBase, (P << 24) | n.imask};
+        }
+#else
+        struct Ent {
+            uint32_t ref;
+            float t;
+        };
+        std::vector<Ent> stack;
+        uint32_t cur = hs.root;
+        for (;;) {
+            cur &= ~0x40000000u;
+            if (cur & RTX_LEAF_FLAG) {
+                const uint32_t first = (cur & 0x3FFFFFFFu) >> 3, cnt = (cur & 7u) + 1u;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    ++nTris;
+                    walk_tri(hs, first + k, r, best, bestSlot, bestPrim);
+                }
+            } else {
+                const Node4& n = hs.nodes[cur];
+                ++nNodes;
+                const float o[3] = {n.ox, n.oy, n.oz};
+                const float sc[3] = {walk_scale(n.ex), walk_scale(n.ey), walk_scale(n.ez)};
+                Ent h[4];
+                int nh = 0;
+                for (int i = 0; i < 4; ++i) {
+                    if (n.child[i] == RTX_EMPTY_CHILD) continue;
+                    float lo[3], hi[3];
+                    for (int a = 0; a < 3; ++a) {
+                        lo[a] = o[a] + (float)n.qlo[a][i] * sc[a];
+                        hi[a] = o[a] + (float)n.qhi[a][i] * sc[a];
+                    }
+                    const float t = walk_slab(r, lo, hi, best);
+                    if (t >= 0.0f) h[nh++] = Ent{n.child[i], t};
+                }
+                std::stable_sort(h, h + nh, [](const Ent& a, const Ent& b) { return a.t < b.t; });
+                for (int i = nh - 1; i >= 1; --i) stack.push_back(h[i]);
+                if (nh > 0) {
+                    cur = h[0].ref;
+                    continue;
+                }
+            }
+            bool found = false;
+            while (!stack.empty()) {
+                const Ent e = stack.back();
+                stack.pop_back();
+                if (e.t <= best * 1.00001f) {
+                    cur = e.ref;
+                    found = true;
+                    break;
+                }
+            }
+            if (!found) break;
+        }
+#endif
+    }
+    *tOut = bestSlot >= 0 ? best : -1.0f;
+    *primOut = bestSlot >= 0 ? (int)bestPrim : -1;
+    counts[0] += nNodes;
+    counts[1] += nTris;
 }

@@ -8,7 +8,7 @@
 #include "../../include/rtx.h"
 
 struct HostScene {
-    std::vector<Node4> nodes;
+    std::vector<BvhNode> nodes;
     std::vector<TriRec> tris;
     std::vector<TriAttr> attrs;
     std::vector<ObjRec> objs;
@@ -24,3 +24,8 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
 // Structural self-check used by the CPU tests: every triangle in exactly one leaf, every child box contains
 // its subtree, quantised boxes are conservative. Returns an empty string when consistent.
 std::string validate_host_scene(const HostScene& hs);
+
+// Host model of the kernels' traversal order for one ray {o.xyz, tmax, d.xyz, -}: closest hit (t and global triangle id, -1 / -1
+// for a miss) among the world-space triangles, counts[0] += nodes visited, counts[1] += triangles tested. Test and
+// measurement aid (rtx_debug_host_walk); no render path calls it.
+void host_walk_closest(const HostScene& hs, const float* ray8, float* tOut, int* primOut, uint64_t counts[2]);

@@ -39,6 +39,35 @@ struct Node4 {
 };
 static_assert(sizeof(Node4) == 64, "Node4 must be 64 bytes");
 
+// The 8-wide form (RTX_BVH8=1): 128-byte nodes with implicit child addressing, after Ylitie, Karras, Laine, "Efficient
+// incoherent ray traversal on GPUs through compressed wide BVHs" (HPG 2017). A node's inner children are consecutive nodes
+// from childBase in slot order, the triangles of its leaf children consecutive records from triBase in slot order, so a
+// node carries two bases and a few masks instead of eight references, and the traversal stack holds one entry per level:
+// the node GROUP {childBase, hit slots still to visit}. Children sit in the slot whose corner of the node they lie towards
+// (bit a of the slot set = high side on axis a), so "slot XOR ray octant" orders them front to back without a sort.
+#ifndef RTX_BVH8
+#define RTX_BVH8 0
+#endif
+#define RTX_LEAF8_MAX 3     // triangles per leaf child the masks have room for (3 bits per slot); the builder emits RTX_MAX_LEAF
+struct Node8 {
+    float ox, oy, oz;       // quantisation origin = node box min
+    uint8_t ex, ey, ez, imask;   // biased exponents of the per-axis scale; imask bit s: slot s holds an inner node
+    uint32_t childBase;     // node index of the first inner child
+    uint32_t triBase;       // record index of the first triangle of the leaf children
+    uint32_t tvalid;        // bit 3s+j: the leaf child in slot s has a j-th triangle; its record is triBase + popcount(tvalid below that bit)
+                            // [31:24] tmask: slot s's subtree (or leaf) holds a surface that lets light through (no TRI_OPAQUE)
+    uint32_t ttrans;        // bit 3s+j: that triangle lets light through; [31:24] valid: slot s holds a child at all
+    uint8_t qlo[3][8];      // [axis][slot], box lo = o + q * scale (rounded down)
+    uint8_t qhi[3][8];      // box hi (rounded up)
+    uint32_t pad[12];
+};
+static_assert(sizeof(Node8) == 128, "Node8 must be 128 bytes");
+#if RTX_BVH8
+typedef Node8 BvhNode;
+#else
+typedef Node4 BvhNode;
+#endif
+
 struct TriRec {
     float v0x, v0y, v0z;
     uint32_t prim;          // global triangle id = faceBase[obj] + face (object order, then face order)
@@ -118,7 +147,7 @@ struct DevLight {
 
 // Everything a kernel needs, passed by value as a kernel argument (lives in SGPRs / kernarg segment).
 struct DevScene {
-    const Node4* nodes;
+    const BvhNode* nodes;
     const TriRec* tris;
     const TriAttr* attrs;
     const ObjRec* objs;

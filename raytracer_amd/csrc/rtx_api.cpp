@@ -320,6 +320,20 @@ int rtx_debug_validate_bvh(const rtx_scene_desc* desc, uint64_t out[3]) {
     return RTX_OK;
 }
 
+// Host model of the traversal (bvh_build.cpp host_walk_closest) over n rays: closest hits and the number of nodes visited /
+// triangles tested. Builds the tree for desc on the host; no device needed, nothing of the render path involved.
+int rtx_debug_host_walk(const rtx_scene_desc* desc, const rtx_ray* rays, size_t n, float* t_out, int* prim_out, uint64_t counts[4]) {
+    if (!desc || (n && (!rays || !t_out || !prim_out)) || !counts) return rtx_fail(RTX_ERR_INVALID, "bad argument");
+    HostScene hs;
+    std::string err;
+    if (!build_host_scene(desc, hs, err)) return rtx_fail(RTX_ERR_INVALID, err);
+    counts[0] = counts[1] = 0;
+    counts[2] = hs.nodes.size();
+    counts[3] = (uint64_t)hs.depth;
+    for (size_t i = 0; i < n; ++i) host_walk_closest(hs, reinterpret_cast<const float*>(rays + i), t_out + i, prim_out + i, counts);
+    return RTX_OK;
+}
+
 int rtx_debug_queue_layout(uint32_t producer_blocks, uint32_t block_threads, uint32_t mult, uint32_t start[64],
                            uint32_t* segment_of_block) {
     if (!producer_blocks || !block_threads || !mult || !start) return rtx_fail(RTX_ERR_INVALID, "bad argument");
@@ -372,7 +386,7 @@ int rtx_scene_info(const rtx_scene* s, uint64_t counts[6], float bounds[6]) {
     if (counts) {
         counts[0] = s->nTris;
         counts[1] = s->nNodes;
-        counts[2] = sizeof(Node4);
+        counts[2] = sizeof(BvhNode);
         counts[3] = sizeof(TriRec);
         counts[4] = s->deviceBytes;
         counts[5] = (uint64_t)s->depth;
