@@ -35,6 +35,18 @@ int orc_scene_create(const rtx_scene_desc* d, void** out) {
 }
 void orc_scene_destroy(void* s) { delete (Scene*)s; }
 
+// The scene graph below rootNode: n nodes, parents before children (parent[i] < i, -1 = child of rootNode), tm12 = node -> parent
+// (3x4 row-major each), mesh[i] = the node's object (index into the scene's meshes, whose geometry is then taken in the
+// node's own coordinates and whose own transform is ignored) or -1. From then on every intersection of this scene walks the
+// tree level by level as IntersectNodeLocal does (IntersectNodeAdapter.h:23-97).
+int orc_scene_set_tree(void* s, int n, const int* parent, const float* tm12, const int* mesh) {
+    Scene* sc = (Scene*)s;
+    for (int i = 0; i < n; ++i)
+        if (parent[i] >= i || mesh[i] >= (int)sc->meshes.size()) return 1;
+    sc->set_tree(n, parent, tm12, mesh);
+    return 0;
+}
+
 int orc_scene_bounds(void* s, float b[6]) {
     Scene* sc = (Scene*)s;
     b[0] = sc->rootBox.pmin.x; b[1] = sc->rootBox.pmin.y; b[2] = sc->rootBox.pmin.z;

@@ -289,9 +289,114 @@ bool Light::intersect(const Ray& ray, Hit& hInfo) const {
     return true;
 }
 
+// ---- the scene graph as the reference walks it (IntersectNodeAdapter.h:23-97), for scenes deeper than one level ----
+// Node::ToNodeCoords / FromNodeCoords and Node::ComputeChildBoundBox belong to the absent framework (scene.h); the
+// conventions are the ones the depth-1 walk below already uses: ray p' = itm * p (translation included), dir' = itm * dir
+// not renormalised; hit p = tm * p, normals by itm^T and renormalised, dpdu / dpdv by tm; a node's child box is the union
+// over its children of the 8 transformed corners of (child's object box + child's child box).
+void Scene::set_tree(int n, const int* parent, const float* tm12, const int* mesh) {
+    tree.assign((size_t)n, TreeNode());
+    treeRoots.clear();
+    for (int i = 0; i < n; ++i) {
+        TreeNode& t = tree[i];
+        t.parent = parent[i];
+        std::memcpy(t.tm.m, tm12 + 12 * (size_t)i, sizeof(float) * 12);
+        t.identity = is_identity(t.tm);
+        t.itm = t.identity ? t.tm : invert(t.tm);
+        t.mesh = mesh[i];
+        if (t.parent >= 0) tree[t.parent].children.push_back(i);
+        else treeRoots.push_back(i);
+    }
+    rootBox = Box();
+    for (int i = n - 1; i >= 0; --i) {   // parents come before their children
+        Box b = tree[i].childBox;
+        if (tree[i].mesh >= 0) b.add(meshes[tree[i].mesh].bounds);
+        if (b.empty()) continue;
+        Box& dst = tree[i].parent >= 0 ? tree[tree[i].parent].childBox : rootBox;
+        for (int c = 0; c < 8; ++c) {
+            V3 p((c & 1) ? b.pmax.x : b.pmin.x, (c & 2) ? b.pmax.y : b.pmin.y, (c & 4) ? b.pmax.z : b.pmin.z);
+            dst.add(tree[i].identity ? p : xf_point(tree[i].tm, p));
+        }
+    }
+}
+
+// IntersectNodeLocal (IntersectNodeAdapter.h:23-97); node = -1 is rootNode (identity, no object)
+bool Scene::intersect_node_local(int node, const Ray& localRay, Hit& outHit, int hitSide, bool useBVH, uint64_t* counters) const {
+    bool anyHit = false;
+    Hit bestLocal;
+    bestLocal.init();
+    bestLocal.z = outHit.z;   // :28
+    const Box& childUnionBox = node < 0 ? rootBox : tree[node].childBox;
+    const bool childUnionMiss = !childUnionBox.empty() && !childUnionBox.intersect(localRay, bestLocal.z);   // :30-32
+    if (node >= 0 && tree[node].mesh >= 0) {   // :35-51
+        const Mesh& m = meshes[tree[node].mesh];
+        const bool bboxOK = m.bounds.empty() || m.bounds.intersect(localRay, bestLocal.z);
+        if (bboxOK) {
+            Hit h;
+            h.init();
+            h.z = bestLocal.z;
+            if (m.intersect_ray(localRay, h, hitSide, useBVH, counters)) {
+                if (h.z > 0.0f && h.z < bestLocal.z) {
+                    bestLocal = h;
+                    bestLocal.obj = tree[node].mesh;
+                    anyHit = true;
+                }
+            }
+        }
+    }
+    if (!childUnionMiss) {   // :54-90
+        const std::vector<int>& kids = node < 0 ? treeRoots : tree[node].children;
+        for (int c : kids) {
+            const TreeNode& child = tree[c];
+            Ray childRay = localRay;   // :62 child->ToNodeCoords(localRay)
+            if (!child.identity) {
+                childRay.p = xf_point(child.itm, localRay.p);
+                childRay.dir = xf_vec(child.itm, localRay.dir);
+            }
+            bool childMaybeHit = false;   // :63-75
+            if (!child.childBox.empty() && child.childBox.intersect(childRay, bestLocal.z)) childMaybeHit = true;
+            if (child.mesh >= 0) {
+                const Box& ob = meshes[child.mesh].bounds;
+                if (ob.empty() || ob.intersect(childRay, bestLocal.z)) childMaybeHit = true;
+            }
+            if (!childMaybeHit) continue;
+            Hit childLocal;
+            childLocal.init();
+            childLocal.z = bestLocal.z;
+            if (intersect_node_local(c, childRay, childLocal, hitSide, useBVH, counters)) {
+                if (childLocal.z > 0.0f && childLocal.z < bestLocal.z) {   // :84
+                    bestLocal = childLocal;
+                    anyHit = true;
+                }
+            }
+        }
+    }
+    if (anyHit) {
+        if (node >= 0 && !tree[node].identity) {   // :93 node->FromNodeCoords(bestLocal)
+            const TreeNode& t = tree[node];
+            bestLocal.p = xf_point(t.tm, bestLocal.p);
+            bestLocal.N = normalized(xf_vec_t(t.itm, bestLocal.N));
+            bestLocal.GN = normalized(xf_vec_t(t.itm, bestLocal.GN));
+            bestLocal.dpdu = xf_vec(t.tm, bestLocal.dpdu);
+            bestLocal.dpdv = xf_vec(t.tm, bestLocal.dpdv);
+        }
+        outHit = bestLocal;
+    }
+    return anyHit;
+}
+
 // IntersectNodeAdapter.h:23-108 applied to the depth-1 tree that CollectSceneNodeObjects flattens
-// (SceneAdapter.h:8-18): rootNode (no object, identity) with one child node per mesh.
+// (SceneAdapter.h:8-18): rootNode (no object, identity) with one child node per mesh. With a node tree set
+// (orc_scene_set_tree) the walk is the reference's, level by level, and the meshes' own transforms are not used.
 bool Scene::intersect_node(const Ray& inRay, Hit& outHit, int hitSide, bool useBVH, uint64_t* counters) const {
+    if (!tree.empty()) {   // IntersectNode :100-108 - rootNode's ToNodeCoords is the identity
+        Hit localHit;
+        localHit.init();
+        localHit.z = outHit.z;
+        const bool hit = intersect_node_local(-1, inRay, localHit, hitSide, useBVH, counters);
+        if (hit) outHit = localHit;
+        return hit;
+    }
     // IntersectNode :100-108 — root ToNodeCoords is identity
     Hit bestLocal;
     bestLocal.init();

@@ -140,6 +140,17 @@ struct Light {
     bool intersect(const Ray& ray, Hit& h) const;  // Shading.cpp:65-86
 };
 
+// A node of the scene graph below rootNode (scene.h of the absent framework: a transform to the parent, an optional object,
+// children). Set by orc_scene_set_tree; without it the scene is the depth-1 tree CollectSceneNodeObjects flattens.
+struct TreeNode {
+    int parent = -1;              // index of the parent node, -1 = child of rootNode
+    M34 tm, itm;                  // node -> parent and its inverse (Node::TransformFrom / TransformTo)
+    bool identity = true;
+    int mesh = -1;                // Node::GetNodeObj(): index into Scene::meshes (geometry in the node's own coordinates), -1 = none
+    std::vector<int> children;
+    Box childBox;                 // Node::GetChildBoundBox(): the children's boxes (objects and their child boxes) in this node's coordinates
+};
+
 struct Scene {
     std::vector<Mesh> meshes;
     std::vector<Material> materials;
@@ -150,6 +161,12 @@ struct Scene {
     float bgEmission = 0;
     Box rootBox;                  // rootNode.GetChildBoundBox()
     std::vector<int> faceBase;    // global triangle index base per mesh
+
+    // the real node tree (IntersectNodeAdapter.h:23-97 level by level) when orc_scene_set_tree has been called
+    std::vector<TreeNode> tree;
+    std::vector<int> treeRoots;   // children of rootNode
+    void set_tree(int n, const int* parent, const float* tm12, const int* mesh);
+    bool intersect_node_local(int node, const Ray& localRay, Hit& out, int hitSide, bool useBVH, uint64_t* counters) const;
 
     bool intersect_node(const Ray& ray, Hit& out, int hitSide, bool useBVH, uint64_t* counters = nullptr) const;
     bool intersect_with_lights(const Ray& ray, Hit& out, int hitSide, bool useBVH = true,

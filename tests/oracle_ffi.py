@@ -62,6 +62,14 @@ class OracleScene:
             self.L.orc_scene_destroy(self.h)
             self.h = None
 
+    def set_tree(self, parent, tms, mesh):
+        """The scene graph below rootNode (orc_scene_set_tree): from now on intersections walk it level by level."""
+        parent = np.ascontiguousarray(parent, np.int32)
+        tms = np.ascontiguousarray(tms, np.float32).reshape(-1, 12)
+        mesh = np.ascontiguousarray(mesh, np.int32)
+        rc = self.L.orc_scene_set_tree(self.h, int(parent.shape[0]), _vp(parent.ctypes.data), _vp(tms.ctypes.data), _vp(mesh.ctypes.data))
+        assert rc == 0, "bad node tree"
+
     def bounds(self):
         b = (C.c_float * 6)()
         self.L.orc_scene_bounds(self.h, b)
