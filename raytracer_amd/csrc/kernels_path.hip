@@ -230,9 +230,9 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
     uint32_t cacheHits = 0;
 #endif
     TravState s;
-    s.cur = RTX_TRAV_DONE;
+    s.cur = RTX_LANE_IDLE;   // a lane's state is its s.cur alone (extend_kernel): -1 a hop that has ended, -2 no segment in the lane
     s.sp = 0;
-    bool active = false, exhausted = false;
+    bool exhausted = false;
     SegWalk walk;
     segq_walk_init(q, walk, gtid >> 6, chunk);
     uint32_t code = 0, entry = 0;
@@ -249,9 +249,9 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
     for (;;) {
         // hops that reached their end are resolved in batches (see extend_kernel): the chain either ends or starts
         // its next hop in the same lane
-        const bool fin = active && s.cur == RTX_TRAV_DONE;
+        const bool fin = s.cur == RTX_TRAV_DONE;
         const unsigned long long finMask = __ballot(fin);
-        const unsigned long long freeMask = finMask | __ballot(!active);
+        const unsigned long long freeMask = finMask | __ballot(s.cur == RTX_LANE_IDLE);
         if (finMask != 0ull && ((uint32_t)__popcll(freeMask) >= SHADOW_REFILL_MIN || freeMask == ~0ull)) {
             // lean kernel: a hop that ends on a hit the reference's box tests would have culled (not checked on the way: see
             // ref_box_hit) is not resolved here - the whole chain is traced again by the general kernel (launch_shadow_culled)
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
             }
             if (culledHop) {
                 hops -= (uint32_t)hop + 1u;   // counted again there
-                active = false;
+                s.cur = RTX_LANE_IDLE;
             } else if (fin && mode != 3 && !trav_verify(s, sc)) {
                 mode = 0;   // general kernels: the hop's hit is culled by its object's box in the reference, traced again without that object
             } else if (fin) {
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
                     float T;
                     if (shadow_hop_end(sc, o, d, maxDist, s.best, (useTransmittance & 1) != 0, hop, visibility, T)) {
                         pool.nee[(size_t)(code & 7u) * pool.capacity + (code >> 3)].w = T;
-                        active = false;
+                        s.cur = RTX_LANE_IDLE;
                         next = false;
                     } else
                         hops++;
@@ -288,13 +288,13 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
                 }
             }
         }
-        const unsigned long long idle = __ballot(!active);
+        const unsigned long long idle = __ballot(s.cur == RTX_LANE_IDLE);
         const uint32_t nIdle = (uint32_t)__popcll(idle);
         if (!exhausted && nIdle >= SHADOW_REFILL_MIN) {
             uint32_t first = 0;
             const uint32_t got = segq_take(q, walk, nIdle, first);
             if (got == 0u) exhausted = true;
-            if (!active) {
+            if (s.cur == RTX_LANE_IDLE) {
                 const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 if (prefix < got) {
                     entry = (XF && items) ? items[first + prefix] : first + prefix;   // (a list: launch_shadow_culled)
@@ -309,7 +309,6 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
                     trav_init(s, sc, RayT{o.x, o.y, o.z, d.x, d.y, d.z, maxDist});
                     mode = 0;
                     hops++;
-                    active = true;
                     // Blocker cache (lean scenes): the opaque triangle that last blocked a ray from this neighbourhood towards this
                     // light is tested before anything else. If it blocks this ray too - a hit that decides the hop,
                     // shadow_hit_decides - the lane starts where a traversal would have arrived after finding it: blocker known,
@@ -339,14 +338,16 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
                 }
             }
         }
-        if (__ballot(active) == 0ull) {
-            if (exhausted) break;
-            continue;
-        }
         {
-            const bool atInner = active && trav_is_inner(s.cur);
-            const bool atLeaf = active && !atInner && s.cur != RTX_TRAV_DONE;
-            const uint32_t nInner = (uint32_t)__popcll(__ballot(atInner)), nLeaf = (uint32_t)__popcll(__ballot(atLeaf));
+            const bool atInner = (int)s.cur >= 0;
+            const bool atLeaf = (int)s.cur < (int)RTX_LANE_IDLE;
+            const unsigned long long innerMask = __ballot(atInner), leafMask = __ballot(atLeaf);
+            if ((innerMask | leafMask) == 0ull) {
+                // nothing to step: hops that have ended are resolved at the top of the loop, a drained queue ends it
+                if (exhausted && __ballot(s.cur == RTX_TRAV_DONE) == 0ull) break;
+                continue;
+            }
+            const uint32_t nInner = (uint32_t)__popcll(innerMask), nLeaf = (uint32_t)__popcll(leafMask);
             if (nLeaf * LEAF_WEIGHT >= nInner) {
                 if (atLeaf) {
 #if SHADOW_ANYHIT

@@ -87,9 +87,12 @@ __global__ __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(XF ?
     TravStack st = make_trav_stack<true>(&lds_stack[threadIdx.x], spill, gtid, gridDim.x * blockDim.x);
     uint32_t nodeCount = 0, triCount = 0, rayCount = 0;
     TravState s;
-    s.cur = RTX_TRAV_DONE;
+    // A lane's state is its s.cur alone, so that every predicate of the loop is one compare on a register (a loop-carried
+    // bool is kept as a lane mask, and the compiler turns a ballot of it into a select and a compare per use):
+    //   (int)cur >= 0   at an inner node          (int)cur < RTX_LANE_IDLE   at a leaf
+    //   cur == RTX_TRAV_DONE (-1)  holds a finished ray, not yet retired      cur == RTX_LANE_IDLE (-2)  holds no ray
+    s.cur = RTX_LANE_IDLE;
     s.sp = 0;
-    bool active = false;      // this lane holds a ray
     bool exhausted = false;   // the queue is drained (wave-uniform)
     SegWalk walk;
     segq_walk_init(q, walk, gtid >> 6, chunk);
@@ -97,42 +100,43 @@ __global__ __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(XF ?
     for (;;) {
         // ---- retire finished rays in batches (a handful of lanes running the epilogue every iteration would cost
         //      more issue slots than the traversal steps themselves), then refill the idle lanes ----
-        const bool fin = active && s.cur == RTX_TRAV_DONE;
+        const bool fin = s.cur == RTX_TRAV_DONE;
         const unsigned long long finMask = __ballot(fin);
-        const unsigned long long freeMask = finMask | __ballot(!active);
+        const unsigned long long freeMask = finMask | __ballot(s.cur == RTX_LANE_IDLE);
         if (finMask != 0ull && ((uint32_t)__popcll(freeMask) >= REFILL_MIN || freeMask == ~0ull)) {
             if (fin && trav_verify(s, sc)) {   // (general kernels: a hit the reference's box tests cull is traced again without that object)
                 if (withLights) intersect_lights(sc, s.r, s.best);
                 hits[rayIndex] = make_float4(s.best.t, s.best.u, s.best.v, __int_as_float(s.best.slot));
                 if (COUNT) rayCount++;
-                active = false;
+                s.cur = RTX_LANE_IDLE;
             }
         }
-        const unsigned long long idle = __ballot(!active);
+        const unsigned long long idle = __ballot(s.cur == RTX_LANE_IDLE);
         const uint32_t nIdle = (uint32_t)__popcll(idle);
         if (!exhausted && nIdle >= REFILL_MIN) {
             uint32_t first = 0;
             const uint32_t got = segq_take(q, walk, nIdle, first);
             if (got == 0u) exhausted = true;
-            if (!active) {
+            if (s.cur == RTX_LANE_IDLE) {
                 const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 if (prefix < got) {
                     rayIndex = items ? items[first + prefix] : first + prefix;   // path slots or identity
                     const float4 a = rays[2 * (size_t)rayIndex], b = rays[2 * (size_t)rayIndex + 1];
                     trav_init(s, sc, RayT{a.x, a.y, a.z, b.x, b.y, b.z, a.w});
-                    active = true;
                 }
             }
         }
-        if (__ballot(active) == 0ull) {
-            if (exhausted) break;
-            continue;
-        }
         // ---- one traversal step for the larger group of lanes ----
         {
-            const bool atInner = active && trav_is_inner(s.cur);
-            const bool atLeaf = active && !atInner && s.cur != RTX_TRAV_DONE;
-            const uint32_t nInner = (uint32_t)__popcll(__ballot(atInner)), nLeaf = (uint32_t)__popcll(__ballot(atLeaf));
+            const bool atInner = (int)s.cur >= 0;
+            const bool atLeaf = (int)s.cur < (int)RTX_LANE_IDLE;
+            const unsigned long long innerMask = __ballot(atInner), leafMask = __ballot(atLeaf);
+            if ((innerMask | leafMask) == 0ull) {
+                // nothing to step: finished rays are retired at the top of the loop, a drained queue ends it
+                if (exhausted && __ballot(s.cur == RTX_TRAV_DONE) == 0ull) break;
+                continue;
+            }
+            const uint32_t nInner = (uint32_t)__popcll(innerMask), nLeaf = (uint32_t)__popcll(leafMask);
 #ifdef TRAV_PROFILE
             if (COUNT && (threadIdx.x & 63u) == 0u) {   // wave-level step statistics (variant builds only)
                 const bool leafStep = nLeaf * LEAF_WEIGHT >= nInner;

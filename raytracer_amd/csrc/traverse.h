@@ -286,6 +286,8 @@ __device__ __forceinline__ void test_primitive(const SC& sc, const float4 a, con
 // wave first descend inner nodes until each holds a leaf (or is done), then all test their leaves together, so
 // the node code and the triangle code each run with as many active lanes as possible.
 #define RTX_TRAV_DONE 0xFFFFFFFFu   // == RTX_EMPTY_CHILD: never a valid child to visit
+#define RTX_LANE_IDLE 0xFFFFFFFEu   // (kernels' lane state, never set by the traversal: "this lane holds no ray"; no leaf reference ends
+                                    //  in 0b110 - a leaf holds at most RTX_MAX_LEAF <= 4 records)
 
 struct TravState {
     RayT r;
