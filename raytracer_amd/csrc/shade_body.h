@@ -143,6 +143,10 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
         do {
             if (h.slot == -1) {
                 // ---- miss: backplate / environment (RayCaster.cpp:362-382) ----
+#ifdef RTX_ABLATE_MISS
+                L = L + beta * 0.5f;
+                break;
+#endif
                 const f3 nd = normalized3(rdir);
                 float uEnv = 0.0f, vEnv = 0.0f;
                 dir_to_screen_uv(cam, nd, uEnv, vEnv);

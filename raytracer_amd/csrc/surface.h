@@ -13,18 +13,15 @@ struct SurfHit {
 };
 
 // TextureFile::Eval of the absent framework: tile, then bilinear with wrap-around (stand-in choice).
-__device__ __forceinline__ f3 tex_texel(const DevTexMap& tm, int x, int y) {
-    const size_t i = (size_t)y * tm.width + x;
-    if (tm.format == RTX_TEX_RGB8) {
-        const uchar4 c = reinterpret_cast<const uchar4*>(tm.texels)[i];
-        return mk3(rtx_unorm8((float)c.x), rtx_unorm8((float)c.y), rtx_unorm8((float)c.z));   // = (float)c.x / 255.0f ... bit for bit
-    }
-    const float4 c = reinterpret_cast<const float4*>(tm.texels)[i];
-    return mk3(c.x, c.y, c.z);
-}
-__device__ __forceinline__ f3 tex_eval_raw(const DevTexMap& tm, f3 uvw) {
-    const int w = tm.width, h = tm.height;
-    if (w + h == 0) return mk3(0.0f);
+// The four texels of a bilinear tap and their weights. A tap's texel loads are independent of each other; they are issued
+// together under ONE format branch (tex_eval_raw_n) - a format test per texel puts a wait for the load just issued between
+// any two of them, and the three taps of a bump lookup were twelve memory round trips in a row (the shade kernel waits on
+// memory for 63 % of a wave's lifetime: profiles/r03/pmc_summary_spp8_r03b.txt).
+struct TexTap {
+    size_t i00, i10, i01, i11;
+    float fx, fy;
+};
+__device__ __forceinline__ TexTap tex_tap(int w, int h, f3 uvw) {
     float ux = uvw.x - (float)(int)uvw.x;
     float uy = uvw.y - (float)(int)uvw.y;
     if (ux < 0.0f) ux += 1.0f;
@@ -33,16 +30,65 @@ __device__ __forceinline__ f3 tex_eval_raw(const DevTexMap& tm, f3 uvw) {
     const float y = (float)h * uy;
     int ix = (int)x;
     int iy = (int)y;
-    const float fx = x - (float)ix;
-    const float fy = y - (float)iy;
+    TexTap t;
+    t.fx = x - (float)ix;
+    t.fy = y - (float)iy;
     if (ix >= w) ix -= (ix / w) * w;
     int ixp = ix + 1;
     if (ixp >= w) ixp -= w;
     if (iy >= h) iy -= (iy / h) * h;
     int iyp = iy + 1;
     if (iyp >= h) iyp -= h;
-    return tex_texel(tm, ix, iy) * ((1 - fx) * (1 - fy)) + tex_texel(tm, ixp, iy) * (fx * (1 - fy)) +
-           tex_texel(tm, ix, iyp) * ((1 - fx) * fy) + tex_texel(tm, ixp, iyp) * (fx * fy);
+    t.i00 = (size_t)iy * w + ix;
+    t.i10 = (size_t)iy * w + ixp;
+    t.i01 = (size_t)iyp * w + ix;
+    t.i11 = (size_t)iyp * w + ixp;
+    return t;
+}
+__device__ __forceinline__ f3 tex_unorm(uchar4 c) {
+    return mk3(rtx_unorm8((float)c.x), rtx_unorm8((float)c.y), rtx_unorm8((float)c.z));   // = (float)c.x / 255.0f ... bit for bit
+}
+__device__ __forceinline__ f3 tex_blend(const TexTap& t, f3 c00, f3 c10, f3 c01, f3 c11) {
+    return c00 * ((1 - t.fx) * (1 - t.fy)) + c10 * (t.fx * (1 - t.fy)) + c01 * ((1 - t.fx) * t.fy) + c11 * (t.fx * t.fy);
+}
+// N bilinear taps of one texture: every texel load of the RGB8 form is in flight before the first conversion.
+template <int N>
+__device__ __forceinline__ void tex_eval_raw_n(const DevTexMap& tm, const f3 (&uvw)[N], f3 (&out)[N]) {
+    const int w = tm.width, h = tm.height;
+    if (w + h == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) out[k] = mk3(0.0f);
+        return;
+    }
+    TexTap t[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) t[k] = tex_tap(w, h, uvw[k]);
+    if (tm.format == RTX_TEX_RGB8) {
+        const uchar4* tx = reinterpret_cast<const uchar4*>(tm.texels);
+        uchar4 c[N][4];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            c[k][0] = tx[t[k].i00];
+            c[k][1] = tx[t[k].i10];
+            c[k][2] = tx[t[k].i01];
+            c[k][3] = tx[t[k].i11];
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) out[k] = tex_blend(t[k], tex_unorm(c[k][0]), tex_unorm(c[k][1]), tex_unorm(c[k][2]), tex_unorm(c[k][3]));
+    } else {
+        const float4* tx = reinterpret_cast<const float4*>(tm.texels);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {   // (16-byte texels: one tap's loads at a time, or three taps would hold 48 registers)
+            const float4 c00 = tx[t[k].i00], c10 = tx[t[k].i10], c01 = tx[t[k].i01], c11 = tx[t[k].i11];
+            out[k] = tex_blend(t[k], mk3(c00.x, c00.y, c00.z), mk3(c10.x, c10.y, c10.z), mk3(c01.x, c01.y, c01.z), mk3(c11.x, c11.y, c11.z));
+        }
+    }
+}
+__device__ __forceinline__ f3 tex_eval_raw(const DevTexMap& tm, f3 uvw) {
+    const f3 in[1] = {uvw};
+    f3 out[1];
+    tex_eval_raw_n<1>(tm, in, out);
+    return out[0];
 }
 __device__ __forceinline__ f3 xf_point3(const float* M, f3 p) {
     return mk3(M[0] * p.x + M[1] * p.y + M[2] * p.z + M[3], M[4] * p.x + M[5] * p.y + M[6] * p.z + M[7],
@@ -270,9 +316,19 @@ __device__ __forceinline__ void apply_bump(const DevScene& sc, const DevMaterial
     float du = 0.001f, dv = 0.001f;
     const int maxDim = max(tm.width, tm.height);
     if (maxDim > 0) du = dv = 1.0f / (float)maxDim;
-    const float h0 = luma1(tex_eval(sc, m.bump_tex, h.uvw));
-    const float hx = luma1(tex_eval(sc, m.bump_tex, h.uvw + mk3(du, 0.0f, 0.0f)));
-    const float hy = luma1(tex_eval(sc, m.bump_tex, h.uvw + mk3(0.0f, dv, 0.0f)));
+    float h0, hx, hy;
+    {
+#ifdef RTX_ABLATE_TEX
+        h0 = hx = hy = 0.5f;
+#else
+        const f3 at[3] = {xf_point3(tm.xf, h.uvw), xf_point3(tm.xf, h.uvw + mk3(du, 0.0f, 0.0f)), xf_point3(tm.xf, h.uvw + mk3(0.0f, dv, 0.0f))};
+        f3 c[3];
+        tex_eval_raw_n<3>(tm, at, c);   // the twelve texels of the three taps in one round trip
+        h0 = luma1(c[0]);
+        hx = luma1(c[1]);
+        hy = luma1(c[2]);
+#endif
+    }
     const float invDu = (fabsf(du) > 1e-6f) ? 1.0f / du : 0.0f;
     const float invDv = (fabsf(dv) > 1e-6f) ? 1.0f / dv : 0.0f;
     const float dHdU = (hx - h0) * invDu * m.bump_scale;
