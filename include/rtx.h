@@ -227,6 +227,7 @@ typedef struct {
     uint64_t shadow_nodes;         /* nodes visited / triangles tested by those launches; only with counters    */
     uint64_t shadow_tris;
     double   nee_ms;               /* the nee_kernel launches alone (also contained in shade_ms)                */
+    uint64_t repacks;              /* bounces that moved their paths to consecutive slots (DESIGN.md 3 "Compaction") */
 } rtx_stats;
 
 /* Photon mapping (PhotonMapBuilder.h:46-54). */

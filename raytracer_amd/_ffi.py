@@ -103,7 +103,7 @@ class Stats(C.Structure):
                 ("shade_ms", C.c_double), ("total_ms", C.c_double), ("extend_launches", C.c_uint64),
                 ("rays_extend", C.c_uint64), ("shade_launches", C.c_uint64), ("vertices", C.c_uint64),
                 ("shadow_launches", C.c_uint64), ("shadow_segments", C.c_uint64), ("shadow_nodes", C.c_uint64),
-                ("shadow_tris", C.c_uint64), ("nee_ms", C.c_double)]
+                ("shadow_tris", C.c_uint64), ("nee_ms", C.c_double), ("repacks", C.c_uint64)]
 
 
 class PhotonParams(C.Structure):

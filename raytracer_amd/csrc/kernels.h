@@ -59,7 +59,10 @@ uint32_t launch_raygen(const DevCamera& cam, const PathPool& pool, const int* pi
 uint32_t launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm, const SegQ& qIn,
                       const uint32_t* queueIn, uint32_t n, int bounce, int maxBounces, unsigned long long seed, int sBase, int S,
                       const int* pixels, const SegQ& qOut, uint32_t* queueOut, const SegQ& qShadow, int materialKinds,
-                      hipStream_t stream);   // materialKinds: bit 0 MtlMicrofacet, bit 1 MtlPhong present
+                      hipStream_t stream, uint32_t repackBase = 0u);   // materialKinds: bit 0 MtlMicrofacet, bit 1 MtlPhong present
+// repackBase != 0: the bounce moves its paths to consecutive slots from repackBase on (pathstate.h "Compaction"); launch_unpack
+// returns the results of the nUsed slots of the compaction area to the slots of the pass when the pass ends
+void launch_unpack(const PathPool& pool, uint32_t nUsed, int nLights, int usePhotons, hipStream_t stream);
 // the (vertex, light) pairs that shade launch (n vertices) has queued in pool.qN, one lane per pair: lobe evaluation, MIS
 // weight, shadow segments appended to qShadow (kernels_nee.hip). The queue must have been scanned; returns the grid size.
 uint32_t launch_nee(const DevScene& sc, const PathPool& pool, uint32_t n, const SegQ& qShadow, int materialKinds, hipStream_t stream);

@@ -116,7 +116,7 @@ __global__ void raygen_kernel(DevCamera cam, PathPool pool, const int* __restric
 
 // ---- shade (per-vertex body: shade_body.h) -----------------------------------------------------------------------
 #ifndef SHADE_WAVES_PER_EU
-#define SHADE_WAVES_PER_EU 3
+#define SHADE_WAVES_PER_EU 4
 #endif
 // (the instantiations with the microfacet / Phong forms compiled in spill 36-74 registers at three waves, yet two waves
 // are slower: C3 scene through them, 32 spp: 96-105 ms against 110-112; the plain form: 91)
@@ -132,12 +132,14 @@ __device__ __forceinline__ void shade_copy_table(T* dst, const T* src, int count
     const uint32_t words = (uint32_t)count * (uint32_t)(sizeof(T) / 4u);
     for (uint32_t k = threadIdx.x; k < words; k += blockDim.x) reinterpret_cast<uint32_t*>(dst)[k] = reinterpret_cast<const uint32_t*>(src)[k];
 }
-template <bool MICRO, bool PHOT, bool PHONG, bool LDSTAB>
+// REPACK: this bounce moves the paths together (pathstate.h "Compaction"): the vertex at queue position i is read at its slot and
+// written to slot wbase + i of the compaction area, where the path lives from here on.
+template <bool MICRO, bool PHOT, bool PHONG, bool LDSTAB, bool REPACK = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES_PER_EU))) void shade_kernel(DevScene scArg, DevCamera cam, PathPool pool, DevPhotonMap pm,
                                                     SegQ qIn, const uint32_t* __restrict__ queueIn, uint32_t n, int bounce,
                                                     int maxBounces, unsigned long long seed, int sBase, int S,
                                                     const int* __restrict__ pixels, SegQ qOut, uint32_t* __restrict__ queueOut,
-                                                    SegQ qShadow, SegQ qNee) {
+                                                    SegQ qShadow, SegQ qNee, uint32_t wbase) {
     __shared__ uint32_t qtab[SEGQ_TABLE_WORDS];
     __shared__ ObjRec sObjs[LDSTAB ? SHADE_LDS_OBJS : 1];
     __shared__ DevMaterial sMtls[LDSTAB ? SHADE_LDS_MTLS : 1];
@@ -175,13 +177,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
         }
         // the lobe evaluation of the vertex's light samples is nee_kernel's (kernels_nee.hip): the body queues the pairs in qNee
         // and leaves the vertex's record at index i of pool.neeCtx
+        uint32_t ws = slot;
+        if (REPACK) {
+            // (a culled vertex stays where it is: the general tail kernel finishes its path there)
+            ws = wbase + i;
+            pool.origin[ws - pool.baseCap] = culled ? 0xFFFFFFFFu : path_origin(pool, slot);
+        }
         if (!culled)
             alive = shade_body<MICRO, false, PHOT, PHONG, true>(sc, cam, pool, pm, slot, ray, HitT{hv.x, hv.y, hv.z, hitSlot}, bounce, maxBounces,
-                                                                seed, sBase, S, pixels, qShadow, i, &qNee, scArg.lights);
+                                                                seed, sBase, S, pixels, qShadow, i, &qNee, scArg.lights, ws);
+        if (REPACK && !culled && slot >= pool.baseCap) pool.origin[slot - pool.baseCap] = 0xFFFFFFFFu;   // moved on from an earlier area
+        slot = ws;
     }
     // ---- surviving paths -> next queue ----
     const uint32_t q = segq_append(qOut, alive, 1u);
     if (alive) queueOut[q] = slot;
+}
+
+// End of a pass that moved paths (pathstate.h "Compaction"): the radiance of every path that finished in the compaction area goes
+// back to the slot the path was generated in, with the NEE of its last vertex added as film_kernel would add it (resolve_add:
+// the same additions in the same order), so that film_kernel finds every sample where ray generation put it.
+__global__ void unpack_kernel(PathPool pool, uint32_t nUsed, int nLights, int usePhotons) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nUsed) return;
+    const uint32_t o = pool.origin[j];
+    if (o == 0xFFFFFFFFu) return;
+    const uint32_t w = pool.baseCap + j;
+    float4 L4 = pool.L[w];
+    f3 L = mk3(L4.x, L4.y, L4.z);
+    resolve_add(pool, w, nLights, usePhotons != 0, L);
+    pool.L[o] = make_float4(L.x, L.y, L.z, L4.w);
+    pool.pendBeta[o] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+}
+void launch_unpack(const PathPool& pool, uint32_t nUsed, int nLights, int usePhotons, hipStream_t stream) {
+    if (!nUsed) return;
+    hipLaunchKernelGGL(unpack_kernel, dim3((nUsed + 255) / 256), dim3(256), 0, stream, pool, nUsed, nLights, usePhotons);
 }
 
 // ---- shadow --------------------------------------------------------------------------------------------------
@@ -608,20 +638,25 @@ uint32_t launch_raygen(const DevCamera& cam, const PathPool& pool, const int* pi
                        initGuides);
     return grid;
 }
+// repackBase: 0 = paths stay in their slots; else the first slot of the compaction area this bounce writes to (>= pool.baseCap)
 uint32_t launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm, const SegQ& qIn,
                       const uint32_t* queueIn, uint32_t n, int bounce, int maxBounces, unsigned long long seed, int sBase, int S,
                       const int* pixels, const SegQ& qOut, uint32_t* queueOut, const SegQ& qShadow, int materialKinds,
-                      hipStream_t stream) {
+                      hipStream_t stream, uint32_t repackBase) {
     if (!n) return 0;
     const uint32_t grid = (n + 255) / 256;
     const bool ldsTab = sc.n_objs <= SHADE_LDS_OBJS && sc.n_mtls <= SHADE_LDS_MTLS && sc.n_texmaps <= SHADE_LDS_TEX;
+#define RTX_LAUNCH_SHADE_R(M, P, G, T, R)                                                                                            \
+    hipLaunchKernelGGL((shade_kernel<M, P, G, T, R>), dim3(grid), dim3(256), 0, stream, sc, cam, pool, pm, qIn, queueIn, n, bounce, maxBounces, \
+                       seed, sBase, S, pixels, qOut, queueOut, qShadow, pool.qN, repackBase)
 #define RTX_LAUNCH_SHADE(M, P, G)                                                                                                    \
-    if (ldsTab)                                                                                                                      \
-        hipLaunchKernelGGL((shade_kernel<M, P, G, true>), dim3(grid), dim3(256), 0, stream, sc, cam, pool, pm, qIn, queueIn, n, bounce, maxBounces, \
-                           seed, sBase, S, pixels, qOut, queueOut, qShadow, pool.qN);                                                \
-    else                                                                                                                             \
-        hipLaunchKernelGGL((shade_kernel<M, P, G, false>), dim3(grid), dim3(256), 0, stream, sc, cam, pool, pm, qIn, queueIn, n, bounce, maxBounces, \
-                           seed, sBase, S, pixels, qOut, queueOut, qShadow, pool.qN)
+    if (ldsTab) {                                                                                                                    \
+        if (repackBase) RTX_LAUNCH_SHADE_R(M, P, G, true, true);                                                                     \
+        else RTX_LAUNCH_SHADE_R(M, P, G, true, false);                                                                               \
+    } else {                                                                                                                         \
+        if (repackBase) RTX_LAUNCH_SHADE_R(M, P, G, false, true);                                                                    \
+        else RTX_LAUNCH_SHADE_R(M, P, G, false, false);                                                                              \
+    }
     // materialKinds: bit 0 = the scene holds MtlMicrofacet, bit 1 = MtlPhong; a caustics map selects the gather
     switch ((materialKinds & 3) | (pm.n > 0 ? 4 : 0)) {
         case 0: RTX_LAUNCH_SHADE(false, false, false); break;
@@ -634,6 +669,7 @@ uint32_t launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& 
         default: RTX_LAUNCH_SHADE(true, true, true); break;
     }
 #undef RTX_LAUNCH_SHADE
+#undef RTX_LAUNCH_SHADE_R
     return grid;
 }
 void launch_shadow(const DevScene& sc, const LaunchCfg& cfg, const PathPool& pool, const SegQ& q, uint32_t n, int useTransmittance) {

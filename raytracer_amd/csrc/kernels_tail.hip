@@ -36,7 +36,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void tail_kernel(DevScene scArg, DevCam
     SegWalk walk;
     segq_walk_init(qIn, walk, gtid >> 6, chunk);
     bool exhausted = false;
-    uint32_t slot = 0u;
+    uint32_t slot = 0u, oslot = 0u;   // oslot: the slot the path was generated in (pathstate.h "Compaction"): its shadow entries are kept there
     bool needExtend = false;    // the path's next ray waits in pool.rays[slot]
     bool haveVertex = false;    // the NEE of the vertex shaded last waits for its shadow results
     int bounce = bounce0;       // bounce index of that next ray
@@ -51,6 +51,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void tail_kernel(DevScene scArg, DevCam
             const uint32_t rank = (uint32_t)__popcll(idleQuads & ((1ull << quadBase) - 1ull));   // idle quads below this one
             if (!busy && rank < got) {
                 slot = queueIn[first + rank];
+                oslot = path_origin(pool, slot);
                 needExtend = true;
                 haveVertex = false;
                 bounce = bounce0;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void tail_kernel(DevScene scArg, DevCam
                 }
             } else if (haveVertex && j - 1 < nL) {
                 if (pool.nee[(size_t)(j - 1) * cap + slot].w >= 0.0f) {
-                    const size_t e = (size_t)slot * mult + (size_t)(j - 1);
+                    const size_t e = (size_t)oslot * mult + (size_t)(j - 1);
                     const float4 a = pool.shadowQ[2 * e], b = pool.shadowQ[2 * e + 1];
                     o = mk3(a.x, a.y, a.z);
                     d = mk3(b.x, b.y, b.z);

@@ -29,7 +29,15 @@ struct DevPhotonMap {
 #define RTX_CULL_CAP 65536u   // entries of PathPool::cullPaths / cullShadows (a 1080p x 128 spp frame holds about 60)
 
 struct PathPool {
-    uint32_t capacity;      // slots
+    uint32_t capacity;      // slots: baseCap of the pass proper + the compaction area behind them
+    // Compaction of the path state inside a pass (rtx_render.cpp "repack"): a path keeps its slot for life, so once most paths
+    // of a pass have ended the survivors' 16-byte fields lie one to a 64-byte memory sector and a late bounce moves four times
+    // the bytes it uses. At a few bounces of a pass shade_kernel therefore writes the state of the paths it shades to fresh,
+    // consecutive slots behind the pass's own (slot >= baseCap) and the path lives on there; origin[] names the slot it was
+    // generated in - the key of its pixel, its sample index and its place in the film - and unpack_kernel returns the final
+    // radiance there when the pass ends.
+    uint32_t baseCap;       // slots of the pass: slot = (chunk * S + s) * 64 + lane
+    uint32_t* origin;       // [slot - baseCap] -> slot of the pass (0xFFFFFFFF: entry not in use, or moved on to a later area)
     // per slot
     float4* rays;           // 2 per slot: {o.xyz, tmax}, {d.xyz, 0}
     float4* hits;           // {t, u, v, bits(slot of triangle / light code)}
@@ -73,3 +81,7 @@ struct PathPool {
     float4* statSum2;       // sum of squares rgb, w = running bestZ
     unsigned long long* rayCounters;  // [0] shadow hops, [1] closest-hit rays of tail_kernel
 };
+// the slot a path was generated in (its pixel and sample index follow from it)
+__device__ __forceinline__ uint32_t path_origin(const PathPool& pool, uint32_t slot) {
+    return slot >= pool.baseCap ? pool.origin[slot - pool.baseCap] : slot;
+}

@@ -199,6 +199,7 @@ static void add_stats(rtx_stats& a, const rtx_stats& s) {
     a.shadow_nodes += s.shadow_nodes;
     a.shadow_tris += s.shadow_tris;
     a.nee_ms += s.nee_ms;
+    a.repacks += s.repacks;
     a.extend_ms += s.extend_ms;
     a.shadow_ms += s.shadow_ms;
     a.shade_ms += s.shade_ms;

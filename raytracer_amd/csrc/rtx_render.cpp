@@ -14,7 +14,8 @@
 struct PathPoolHost {
     PathPool dev{};
     std::vector<void*> allocs;
-    uint32_t capacity = 0;
+    uint32_t capacity = 0;        // slots of a pass
+    uint32_t extra = 0;           // slots of the compaction area behind them (pathstate.h "Compaction")
     int nLights = 0;
     size_t framePixels = 0;
     bool hasCaustic = false;
@@ -55,6 +56,7 @@ struct PathPoolHost {
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         events.clear();
         capacity = 0;
+        extra = 0;
         framePixels = 0;
         bytes = 0;
     }
@@ -80,33 +82,46 @@ static int pool_alloc(PathPoolHost* ph, T** out, size_t count) {
     return RTX_OK;
 }
 
-static int ensure_pool(rtx_scene* s, uint32_t slots, size_t framePixels, size_t listPixels, bool caustic) {
+// slots of the compaction area for passes of `slots` paths that are first moved together when 1/div of them are left and again
+// whenever 1/step of the last count is left: slots / div * (1 + 1/step + 1/step^2 + ...)
+static uint32_t repack_extra(uint32_t slots, int div, int step) {
+    if (div <= 0) return 0u;
+    return (uint32_t)(((size_t)slots / (size_t)div) * (size_t)step / (size_t)(step - 1)) + 1024u;
+}
+
+static int ensure_pool(rtx_scene* s, uint32_t slots, size_t framePixels, size_t listPixels, bool caustic, uint32_t extra) {
     PathPoolHost* ph = reinterpret_cast<PathPoolHost*>(s->pool);
     const int nL = std::max(1, s->dev.n_lights);
-    if (ph && ph->capacity >= slots && ph->framePixels >= std::max(framePixels, listPixels) && ph->nLights == nL &&
+    if (ph && ph->capacity >= slots && ph->extra >= extra && ph->framePixels >= std::max(framePixels, listPixels) && ph->nLights == nL &&
         (ph->hasCaustic || !caustic))
         return RTX_OK;
     rtx_scene_release_pool(s);
     ph = new PathPoolHost();
     s->pool = reinterpret_cast<PathPool*>(ph);
     ph->capacity = slots;
+    ph->extra = extra;
     ph->nLights = nL;
     ph->framePixels = std::max(framePixels, listPixels);
     ph->hasCaustic = caustic;
     PathPool& d = ph->dev;
-    d.capacity = slots;
+    // the arrays a path reads and writes on its way hold the compaction area too; the queues and what belongs to a sample's place
+    // in the pass (guides, film position) are laid out for the slots of a pass
+    const size_t all = (size_t)slots + extra;
+    d.capacity = (uint32_t)all;
+    d.baseCap = slots;   // (render_impl sets it for each pass)
     int rc;
 #define PA(field, count) \
     if ((rc = pool_alloc(ph, &d.field, (count))) != RTX_OK) return rc;
-    PA(rays, 2 * (size_t)slots);
-    PA(hits, slots);
-    PA(L, slots);
-    PA(beta, slots);
-    PA(medium, slots);
-    PA(prevP, slots);
-    PA(pendBeta, slots);
-    PA(nee, (size_t)nL * slots);
-    PA(caustic, caustic ? slots : 1);
+    PA(rays, 2 * all);
+    PA(hits, all);
+    PA(L, all);
+    PA(beta, all);
+    PA(medium, all);
+    PA(prevP, all);
+    PA(pendBeta, all);
+    PA(nee, (size_t)nL * all);
+    PA(caustic, caustic ? all : 1);
+    PA(origin, extra);
     PA(albedo, slots);
     PA(normal, slots);
     PA(samplePos, slots);
@@ -299,6 +314,21 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
     std::memset(&pmGlobal, 0, sizeof(pmGlobal));
     if (usePhotons && legacy) photon_device_map(photons, 0, pmGlobal);   // gathered in legacy mode only (Shading_Legacy.cpp:440-444)
 
+    // Compaction of the path state inside a pass (pathstate.h): the bounce that first finds at most 1/repackDiv of the pass's
+    // paths alive writes their state to consecutive slots behind the pass's own, and so does every later bounce that finds
+    // 1/repackStep of the last such count; bounces of fewer than repackMin paths are left alone (the tail kernel is about to
+    // take them). The move itself is free - the bounce writes its paths' state anyway - and the area costs slots / 4 of the
+    // per-path arrays (C3: 13 GB). Measured on the C3 frame: 777.5 ms without, 766 / 760 / 755 ms with (8, 4) / (6, 3) / (8, 2).
+    // Results do not depend on it. RTX_AMD_REPACK=0 switches it off; RTX_AMD_REPACK_DIV / _STEP / _MIN set the three numbers
+    // (tests force a move at the first bounce of tiny passes with DIV=1, MIN=0).
+    int repackDiv = legacy ? 0 : 8;
+    uint32_t repackMin = 4u * RTX_TAIL_MAX_PATHS;
+    if (const char* e = std::getenv("RTX_AMD_REPACK")) repackDiv = std::atoi(e) != 0 ? repackDiv : 0;
+    if (const char* e = std::getenv("RTX_AMD_REPACK_DIV")) repackDiv = repackDiv > 0 ? std::max(1, std::atoi(e)) : 0;
+    if (const char* e = std::getenv("RTX_AMD_REPACK_MIN")) repackMin = (uint32_t)std::atol(e);
+    int repackStep = 2;
+    if (const char* e = std::getenv("RTX_AMD_REPACK_STEP")) repackStep = std::max(2, std::atoi(e));
+
     // path pool sizing: S samples per pixel per pass
     int S = rp->samples_per_pass;
     if (S <= 0) {
@@ -306,7 +336,8 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
         // so fewer, larger passes amortise that tail. Use up to 60 % of the free memory, at most 170 GB.
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = (size_t)8 << 30;
-        const size_t perSlot = 192 + 128 + 80 * (size_t)std::max(1, s->dev.n_lights);   // + NEE record, + 32 B per light of NEE queue
+        size_t perSlot = 192 + 128 + 80 * (size_t)std::max(1, s->dev.n_lights);   // + NEE record, + 32 B per light of NEE queue
+        if (repackDiv > 0) perSlot += (148 + 16 * (size_t)std::max(1, s->dev.n_lights)) * (size_t)repackStep / (size_t)(repackStep - 1) / (size_t)repackDiv + 1;   // compaction area
         const size_t budget = std::min<size_t>((size_t)(0.6 * (double)freeB), (size_t)170 << 30);
         const size_t target = std::max<size_t>(budget / perSlot, 1u << 20);
         S = (int)std::max<size_t>(1, std::min<size_t>((size_t)perRound, target / std::max<uint32_t>(nPix, 1)));
@@ -317,14 +348,15 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
         }
     }
     S = std::min(S, perRound);
-    // slot * 8 + light must fit 32 bits (shadow queue entries)
-    while (S > 1 && (size_t)nPix * S > 0x1FFFFFFFull) --S;
-    if ((size_t)nPix * S > 0x1FFFFFFFull) return rtx_fail(RTX_ERR_TOO_LARGE, "more than 2^29 path slots per pass");
+    // slot * 8 + light must fit 32 bits (shadow queue entries), for the slots of the compaction area too
+    auto all_slots = [&](int Sx) { return (size_t)nPix * Sx + repack_extra((uint32_t)std::min<size_t>((size_t)nPix * Sx, 0xFFFFFFFFull), repackDiv, repackStep); };
+    while (S > 1 && all_slots(S) > 0x1FFFFFFFull) --S;
+    if (all_slots(S) > 0x1FFFFFFFull) return rtx_fail(RTX_ERR_TOO_LARGE, "more than 2^29 path slots per pass");
     // shadow queue entries are indexed with 32 bits
     while (S > 1 && ((size_t)nPix * S + 256) * (size_t)std::max(1, s->dev.n_lights) > 0xFFFFFFFFull) --S;
     if (((size_t)nPix * S + 256) * (size_t)std::max(1, s->dev.n_lights) > 0xFFFFFFFFull)
         return rtx_fail(RTX_ERR_TOO_LARGE, "more than 2^32 shadow segments per pass");
-    if ((rc = ensure_pool(s, nPix * (uint32_t)S, (size_t)W * H, nPix, usePhotons)) != RTX_OK) return rc;
+    if ((rc = ensure_pool(s, nPix * (uint32_t)S, (size_t)W * H, nPix, usePhotons, repack_extra(nPix * (uint32_t)S, repackDiv, repackStep))) != RTX_OK) return rc;
     PathPoolHost* ph = reinterpret_cast<PathPoolHost*>(s->pool);
     PathPool pool = ph->dev;
     if (spec) {
@@ -419,6 +451,8 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
             launch_segq_scan(sqIn, gridGen, 256, 1, pool.totals, 2, st);
             uint32_t n = (uint32_t)(curValid * (size_t)Sp);   // = totals[2]: every valid pixel generates Sp paths
             out.paths += n;
+            pool.baseCap = nPix * (uint32_t)Sp;   // the compaction area starts behind this pass's slots
+            uint32_t extraUsed = 0, lastRepackN = 0;
             if (legacy && n > 0 && !ph->legacyState) {
                 if ((rc = pool_alloc(ph, &ph->legacyState, legacy_state_bytes(s->cfg))) != RTX_OK) {
                     rtx_scene_release_pool(s);
@@ -453,9 +487,16 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 }
                 // shade: the vertex itself (hit, bump, emission, BSDF sample, next ray); nee: its light samples, one lane per
                 // (vertex, light), which appends the shadow segments (kernels_nee.hip)
+                uint32_t repackBase = 0u;
+                if (repackDiv > 0 && n > repackMin && n <= ph->extra - extraUsed && n <= (lastRepackN ? lastRepackN / (uint32_t)repackStep : pool.baseCap / (uint32_t)repackDiv)) {
+                    repackBase = pool.baseCap + extraUsed;   // this bounce writes its paths to consecutive slots from here on
+                    extraUsed += n;
+                    lastRepackN = n;
+                    out.repacks++;
+                }
                 tm.begin(2, st);
                 const uint32_t gridShade = launch_shade(s->dev, dc, pool, pm, sqIn, qin, n, bounce, rp->max_bounces, rp->seed, sBase, Sp,
-                                                        curPixels, sqOut, qout, pool.qS, shadeKinds, st);
+                                                        curPixels, sqOut, qout, pool.qS, shadeKinds, st, repackBase);
                 tm.end(st);
                 launch_segq_scan2(sqOut, gridShade, 1, pool.qN, gridShade, shadowMult, 256, pool.totals, st);   // totals[0] paths alive, [1] pairs
                 tm.begin(3, st);
@@ -526,6 +567,8 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 sidePending = false;
             }
             // a pass interrupted by rtx_cancel holds unfinished paths: it is dropped, earlier passes stay
+            if (!s->cancel.load(std::memory_order_relaxed) && extraUsed)
+                launch_unpack(pool, extraUsed, s->dev.n_lights, pm.n > 0 ? 1 : 0, st);   // results of the moved paths back to their samples' slots
             if (!s->cancel.load(std::memory_order_relaxed))
                 launch_film(pool, *film, curPixels, nPix, Sp, W, H, rp->filter_type, rp->filter_radius,
                             (done == 0 && (spec ? spec->resetZ != 0 : round == 1)) ? 1 : 0, samplesOut, sBase, sppMax,

@@ -100,12 +100,17 @@ __device__ __forceinline__ void resolve_slot(const PathPool& pool, uint32_t slot
 // cerealBar.xml is MtlBlinn, textured in Diffuse, Emission and bump only).
 // SPLIT: the lobe evaluation of the light loop is left to nee_kernel (kernels_nee.hip): the body samples the lights, appends
 // the (vertex, light) pairs that can contribute to the NEE queue qNee and writes the vertex's record (nee_ctx.h) at neeIndex.
+// ws: the slot the vertex's results are written to - `slot` itself, or a fresh slot of the compaction area when this bounce
+// moves the paths together (pathstate.h "Compaction"; shade_kernel<..., REPACK>): everything the body reads is at `slot`,
+// everything it leaves for later kernels (path state, next ray, NEE records and their slot word) at ws. The first-hit guides
+// stay with the slot the path was generated in, where film_kernel looks for them.
 template <bool MICRO, bool TAIL, bool PHOT = true, bool PHONG = true, bool SPLIT = false>
 __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pmArg,
                                            uint32_t slot, const RayT& ray, const HitT& h, int bounce, int maxBounces,
                                            unsigned long long seed, int sBase, int S, const int* __restrict__ pixels,
                                            const SegQ& qShadow, uint32_t neeIndex = 0u, const SegQ* qNee = nullptr,
-                                           const DevLight* lightsArg = nullptr) {
+                                           const DevLight* lightsArg = nullptr, uint32_t ws = 0xFFFFFFFFu) {
+    if (ws == 0xFFFFFFFFu) ws = slot;
     // the lights, read where the kernel's argument holds them: shade_kernel shades with a copy of the scene descriptor whose
     // table pointers lead to LDS, and an array indexed at run time would keep that whole copy in scratch memory
     const DevLight* lights = lightsArg ? lightsArg : sc.lights;
@@ -133,8 +138,9 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
         uint32_t flags = __float_as_uint(m4.w);
         f3 mediumAbs = mk3(m4.x, m4.y, m4.z);
         const f3 rdir = mk3(ray.dx, ray.dy, ray.dz), rorg = mk3(ray.ox, ray.oy, ray.oz);
-        // pixel / sample of this slot -> RNG key
-        const uint32_t lane64 = slot & 63u, cs = slot >> 6;
+        // pixel / sample of this path -> RNG key
+        const uint32_t oslot = path_origin(pool, slot);
+        const uint32_t lane64 = oslot & 63u, cs = oslot >> 6;
         const int pix = pixels[(cs / (uint32_t)S) * 64u + lane64];
         const int sIdx = sBase + (int)(cs % (uint32_t)S);
         bool pending = false;   // NEE of this bounce to be resolved
@@ -159,8 +165,8 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
                 if (bounce == 0) {
                     const f3 vis = hasBackground ? backplate : envLight;
                     L = L + beta * (vis + bgEmit);
-                    pool.albedo[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // no first hit: no guides (raygen leaves them to this kernel)
-                    pool.normal[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    pool.albedo[oslot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // no first hit: no guides (raygen leaves them to this kernel)
+                    pool.normal[oslot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 } else {
                     L = L + beta * (envLight + bgEmit);
                 }
@@ -195,8 +201,8 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
                 L4.w = hitDist;
                 const f3 alb = (mtl && !micro) ? eval_tc(sc, mtl->kd, mtl->kd_tex, sx.uvw) : mk3(0.5f);
                 const f3 fn = safe_normalize3(sh.GN);
-                pool.albedo[slot] = make_float4(alb.x, alb.y, alb.z, 1.0f);
-                pool.normal[slot] = make_float4(fn.x, fn.y, fn.z, 1.0f);
+                pool.albedo[oslot] = make_float4(alb.x, alb.y, alb.z, 1.0f);
+                pool.normal[oslot] = make_float4(fn.x, fn.y, fn.z, 1.0f);
             }
 
             if (sh.light >= 0) {   // :410-439
@@ -293,8 +299,8 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
                 if (lightMask) {
                     const uint32_t nf = (sx.front ? NEEF_FRONT : 0u) | (phong ? NEEF_PHONG : 0u) | (wantCaustic ? NEEF_CAUSTIC : 0u);
                     float4* rec = pool.neeCtx + neeIndex;
-                    if (micro) nee_ctx_store_micro(rec, pool.neeStride, slot, nf, sh.p, sx.GN, mctx);
-                    else nee_ctx_store(rec, pool.neeStride, slot, nf, sh.p, sx.GN, ctx);
+                    if (micro) nee_ctx_store_micro(rec, pool.neeStride, ws, nf, sh.p, sx.GN, mctx);
+                    else nee_ctx_store(rec, pool.neeStride, ws, nf, sh.p, sx.GN, ctx);
                     pending = true;
                     pendMask = lightMask;
                 }
@@ -334,15 +340,17 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
                             const f3 so = offset_point(sh.p, sx.GN, ldir);
                             const f3 sd = safe_normalize3(ldir);
                             // wave-wide append of the lanes that reach this point (ballot counts active lanes only)
-                            const uint32_t qs = TAIL ? slot * shadowMult + (uint32_t)l : segq_append(qShadow, true, shadowMult);
+                            // (tail_kernel: a fixed entry per path and light, by the slot the path was generated in - the queue arrays
+                            // are laid out for the slots of the pass)
+                            const uint32_t qs = TAIL ? oslot * shadowMult + (uint32_t)l : segq_append(qShadow, true, shadowMult);
                             pool.shadowQ[2 * (size_t)qs] = make_float4(so.x, so.y, so.z, shadowMax);
-                            pool.shadowQ[2 * (size_t)qs + 1] = make_float4(sd.x, sd.y, sd.z, __uint_as_float(slot * 8u + (uint32_t)l));
+                            pool.shadowQ[2 * (size_t)qs + 1] = make_float4(sd.x, sd.y, sd.z, __uint_as_float(ws * 8u + (uint32_t)l));
                         }
                     }
-                    pool.nee[(size_t)l * cap + slot] = contrib;
+                    pool.nee[(size_t)l * cap + ws] = contrib;
                 }
             }
-            if (pending) pool.pendBeta[slot] = make_float4(beta.x, beta.y, beta.z, (float)pendMask);
+            if (pending) pool.pendBeta[ws] = make_float4(beta.x, beta.y, beta.z, (float)pendMask);
 
             if (pm.n > 0) {   // :508-522 (scaled by the visibility in resolve_add)
                 float4 cz = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -353,11 +361,11 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
                         irrad = irrad * 0.1f;   // kCausticBoost
                         const f3 t = kd * (1.0f / PI_F) * irrad;
                         cz = make_float4(t.x, t.y, t.z, 1.0f);
-                        if (!pending) pool.pendBeta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
+                        if (!pending) pool.pendBeta[ws] = make_float4(beta.x, beta.y, beta.z, 0.0f);
                         pending = true;
                     }
                 }
-                pool.caustic[slot] = cz;
+                pool.caustic[ws] = cz;
             }
 
             // ---- BSDF sampling for the next bounce (:525-566) ----
@@ -369,7 +377,7 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
             beta = beta * (bsd.mult / pdfThroughput);
             lastPdf = bsd.prob;
             flags = (flags & ~PF_LAST_DELTA) | (bsd.dist < 0.0f ? PF_LAST_DELTA : 0u);
-            pool.prevP[slot] = make_float4(sh.p.x, sh.p.y, sh.p.z, 0.0f);
+            pool.prevP[ws] = make_float4(sh.p.x, sh.p.y, sh.p.z, 0.0f);
             flags |= PF_HAS_PREV;
             if (bsd.lobe & LOBE_TRANSMISSION) {
                 if (sx.front) {
@@ -389,17 +397,17 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
             if (bounce + 1 >= maxBounces) break;
             const f3 no = offset_point(sh.p, sx.GN, nextDir);
             const f3 nd = safe_normalize3(nextDir);
-            pool.rays[2 * (size_t)slot] = make_float4(no.x, no.y, no.z, RTX_BIG);
-            pool.rays[2 * (size_t)slot + 1] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+            pool.rays[2 * (size_t)ws] = make_float4(no.x, no.y, no.z, RTX_BIG);
+            pool.rays[2 * (size_t)ws + 1] = make_float4(nd.x, nd.y, nd.z, 0.0f);
             alive = true;
         } while (false);
 
-        pool.L[slot] = make_float4(L.x, L.y, L.z, L4.w);
-        pool.beta[slot] = make_float4(beta.x, beta.y, beta.z, lastPdf);
-        pool.medium[slot] = make_float4(mediumAbs.x, mediumAbs.y, mediumAbs.z, __uint_as_float(flags));
+        pool.L[ws] = make_float4(L.x, L.y, L.z, L4.w);
+        pool.beta[ws] = make_float4(beta.x, beta.y, beta.z, lastPdf);
+        pool.medium[ws] = make_float4(mediumAbs.x, mediumAbs.y, mediumAbs.z, __uint_as_float(flags));
         if (!pending) {
             // mark "nothing to resolve" for resolve_add
-            pool.pendBeta[slot] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+            pool.pendBeta[ws] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
         }
     }
     return alive;

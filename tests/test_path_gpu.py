@@ -181,6 +181,25 @@ def test_scheduling_switches_do_not_change_results(small, monkeypatch):
     loop, _ = gs.render_samples(cam, rp)
     monkeypatch.delenv("RTX_AMD_TAIL_PATHS")
     assert np.array_equal(loop, base)
+    # compaction of the path state inside a pass: forced at the first bounce of this small pass and at every
+    # bounce that finds a quarter of the last count; the paths then end in the bounce loop (tail kernel off), in the tail
+    # kernel, or are never moved (switched off)
+    assert st0["repacks"] == 0                                      # (a pass this small is not moved by default)
+    monkeypatch.setenv("RTX_AMD_REPACK_DIV", "1")
+    monkeypatch.setenv("RTX_AMD_REPACK_MIN", "0")
+    moved_tail, st2 = gs.render_samples(cam, rp)
+    monkeypatch.setenv("RTX_AMD_TAIL_PATHS", "0")
+    moved, st3 = gs.render_samples(cam, rp)
+    monkeypatch.delenv("RTX_AMD_TAIL_PATHS")
+    monkeypatch.delenv("RTX_AMD_REPACK_DIV")
+    monkeypatch.delenv("RTX_AMD_REPACK_MIN")
+    assert st2["repacks"] >= 1 and st3["repacks"] >= 3
+    assert np.array_equal(moved_tail, base) and np.array_equal(moved, base)
+    assert st3["rays_shadow"] == st0["rays_shadow"] and st3["rays_bounce"] == st0["rays_bounce"]
+    monkeypatch.setenv("RTX_AMD_REPACK", "0")
+    fixed, st4 = gs.render_samples(cam, rp)
+    monkeypatch.delenv("RTX_AMD_REPACK")
+    assert st4["repacks"] == 0 and np.array_equal(fixed, base)
 
 
 @pytest.mark.parametrize("mode", [_ffi.SHADING_PATH, _ffi.SHADING_LEGACY])
