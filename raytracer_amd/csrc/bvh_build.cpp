@@ -757,6 +757,26 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
             trans = out.nodes[out.root].pad[1] != 0u;
         if (trans) out.root |= 0x40000000u;
     }
+    // TRI_INTERIOR (layout.h): world-space triangles that no hit below TRI_INTERIOR_TMAX can place within well_inside_box's margin
+    // of a face of the root's box or of their object's box - twice that margin, so that the rounding of a hit point o + d t
+    // (a few ulps of its terms) cannot matter
+    for (TriRec& r : out.tris) {
+        if (r.kind != 0u) continue;
+        const uint32_t obj = r.obj & TRI_OBJ_MASK;
+        if (obj >= out.objXf.size()) continue;
+        const float v[3][3] = {{r.v0x, r.v0y, r.v0z}, {r.v0x + r.e1x, r.v0y + r.e1y, r.v0z + r.e1z}, {r.v0x + r.e2x, r.v0y + r.e2y, r.v0z + r.e2z}};
+        bool interior = true;
+        const float* boxes[2] = {out.bounds, out.objXf[obj].box};
+        for (int b = 0; b < 2 && interior; ++b)
+            for (int a = 0; a < 3 && interior; ++a) {
+                const float lo = std::min(v[0][a], std::min(v[1][a], v[2][a])), hi = std::max(v[0][a], std::max(v[1][a], v[2][a]));
+                const float mag = std::max(std::fabs(lo), std::fabs(hi));
+                const float ext = boxes[b][3 + a] - boxes[b][a];
+                const float eps = 2.0f * (1e-3f * ext + 1e-5f * (mag + TRI_INTERIOR_TMAX)) + 1e-4f * (1.0f + mag);
+                interior = ext > 0.0f && lo > boxes[b][a] + eps && hi < boxes[b][3 + a] - eps;
+            }
+        if (interior) r.obj |= TRI_INTERIOR;
+    }
     return true;
 #endif
 }

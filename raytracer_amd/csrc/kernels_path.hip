@@ -115,8 +115,14 @@ __global__ void raygen_kernel(DevCamera cam, PathPool pool, const int* __restric
 }
 
 // ---- shade (per-vertex body: shade_body.h) -----------------------------------------------------------------------
+// Waves per SIMD: the instantiation for plain Blinn scenes without a caustics map fits 128 registers without a spill and runs
+// four (C3 frame: 767 ms against 776 at three); the ones with the microfacet / Phong forms or the photon gather compiled in
+// would spill 16-24 registers there and stay at three.
 #ifndef SHADE_WAVES_PER_EU
 #define SHADE_WAVES_PER_EU 4
+#endif
+#ifndef SHADE_WAVES_PER_EU_GENERAL
+#define SHADE_WAVES_PER_EU_GENERAL 3
 #endif
 // (the instantiations with the microfacet / Phong forms compiled in spill 36-74 registers at three waves, yet two waves
 // are slower: C3 scene through them, 32 spp: 96-105 ms against 110-112; the plain form: 91)
@@ -135,7 +141,7 @@ __device__ __forceinline__ void shade_copy_table(T* dst, const T* src, int count
 // REPACK: this bounce moves the paths together (pathstate.h "Compaction"): the vertex at queue position i is read at its slot and
 // written to slot wbase + i of the compaction area, where the path lives from here on.
 template <bool MICRO, bool PHOT, bool PHONG, bool LDSTAB, bool REPACK = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES_PER_EU))) void shade_kernel(DevScene scArg, DevCamera cam, PathPool pool, DevPhotonMap pm,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MICRO || PHOT || PHONG) ? SHADE_WAVES_PER_EU_GENERAL : SHADE_WAVES_PER_EU))) void shade_kernel(DevScene scArg, DevCamera cam, PathPool pool, DevPhotonMap pm,
                                                     SegQ qIn, const uint32_t* __restrict__ queueIn, uint32_t n, int bounce,
                                                     int maxBounces, unsigned long long seed, int sBase, int S,
                                                     const int* __restrict__ pixels, SegQ qOut, uint32_t* __restrict__ queueOut,
@@ -165,28 +171,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES
         const float4 hv = pool.hits[slot];
         const RayT ray{ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, ra.w};
         const int hitSlot = __float_as_int(hv.w);
-        // a hit that the reference's box tests would have culled (lean extend kernel: not checked there): the vertex is left
-        // alone and the path goes to the general tail kernel, which traces its ray again (rtx_render.cpp)
+        // culled: a hit that the reference's box tests would have removed (lean extend kernel: not checked there) - the body
+        // leaves the vertex alone and the path goes to the general tail kernel, which traces its ray again (shade_body.h)
         bool culled = false;
-        if (pool.cullPaths && hitSlot >= 0 && !ref_reaches_triangle<false>(scArg, ray, hitSlot, hv.x)) {
-            const uint32_t k = atomicAdd(&pool.totals[4], 1u);
-            if (k < RTX_CULL_CAP) {
-                pool.cullPaths[k] = slot;
-                culled = true;
-            }
-        }
         // the lobe evaluation of the vertex's light samples is nee_kernel's (kernels_nee.hip): the body queues the pairs in qNee
         // and leaves the vertex's record at index i of pool.neeCtx
-        uint32_t ws = slot;
+        const uint32_t ws = REPACK ? wbase + i : slot;
+        const uint32_t os = REPACK ? path_origin(pool, slot) : 0u;
+        alive = shade_body<MICRO, false, PHOT, PHONG, true>(sc, cam, pool, pm, slot, ray, HitT{hv.x, hv.y, hv.z, hitSlot}, bounce, maxBounces,
+                                                            seed, sBase, S, pixels, qShadow, i, &qNee, scArg.lights, ws, &culled);
         if (REPACK) {
             // (a culled vertex stays where it is: the general tail kernel finishes its path there)
-            ws = wbase + i;
-            pool.origin[ws - pool.baseCap] = culled ? 0xFFFFFFFFu : path_origin(pool, slot);
+            pool.origin[ws - pool.baseCap] = culled ? 0xFFFFFFFFu : os;
+            if (!culled && slot >= pool.baseCap) pool.origin[slot - pool.baseCap] = 0xFFFFFFFFu;   // moved on from an earlier area
         }
-        if (!culled)
-            alive = shade_body<MICRO, false, PHOT, PHONG, true>(sc, cam, pool, pm, slot, ray, HitT{hv.x, hv.y, hv.z, hitSlot}, bounce, maxBounces,
-                                                                seed, sBase, S, pixels, qShadow, i, &qNee, scArg.lights, ws);
-        if (REPACK && !culled && slot >= pool.baseCap) pool.origin[slot - pool.baseCap] = 0xFFFFFFFFu;   // moved on from an earlier area
         slot = ws;
     }
     // ---- surviving paths -> next queue ----
@@ -245,9 +243,13 @@ __device__ __forceinline__ uint32_t blocker_key(const DevScene& sc, const PathPo
 }
 // COUNT: nodes visited and triangles tested are tallied (counters[3], [4]) - the instrumented build behind rtx_set_counters, which
 // gives the bench the algorithmic bytes of a shadow hop (48 + nodes x 64 + triangles x 48)
+// (the general kernel runs best at four waves per SIMD - 4 / 5 / 6: 64 / 85 / 134 ms on the C3 scene forced through it - and sits
+// right at that register limit: it is told to stay there; the lean kernels are left to the compiler: 78-91 registers, five or six waves)
 template <bool XF, bool CULL = false, bool COUNT = false>
 #ifdef SHADOW_WAVES_PER_EU
 __attribute__((amdgpu_waves_per_eu(SHADOW_WAVES_PER_EU)))
+#else
+__attribute__((amdgpu_waves_per_eu(XF ? 4 : 6)))   // (lean kernel with the box-cull checks: eight registers spilled at six waves, and still 179 -> 171 ms per C3 frame against five)
 #endif
 __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, PathPool pool, SegQ q, int useTransmittance, uint2* spill,
                                                             uint32_t chunk, const uint32_t* __restrict__ items, unsigned long long* counters) {
@@ -288,7 +290,9 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
             bool culledHop = false;
             // (measured: the objects' boxes in LDS and the best hit's object word kept in a register - no memory to wait for
             // here - cost more in the traversal loop than they save: 317 ms per C3 frame against 191)
-            if (!XF && CULL && fin && mode != 3 && pool.cullShadows && s.best.slot >= 0 && !ref_reaches_triangle<true>(scArg, s.r, s.best.slot, s.best.t)) {
+            // (a triangle well inside both boxes - TRI_INTERIOR of the word kept from the triangle test, most of them - needs no fetch)
+            if (!XF && CULL && fin && mode != 3 && pool.cullShadows && s.best.slot >= 0 && !ref_reaches_interior(s.bestWord, s.r, s.best.t) &&
+                !ref_reaches_triangle<true>(scArg, s.r, s.best.slot, s.best.t)) {
                 const uint32_t k = atomicAdd(&pool.totals[5], 1u);
                 if (k < RTX_CULL_CAP) {
                     pool.cullShadows[k] = entry;
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
                         if (cand >= 0) {
                             const float4* tris4 = reinterpret_cast<const float4*>(sc.tris);
                             const float4 ta = tris4[(size_t)cand * 3 + 0], tb = tris4[(size_t)cand * 3 + 1], tc = tris4[(size_t)cand * 3 + 2];
-                            test_triangle(ta, tb, tc, s.r, RTX_HIT_FRONT_AND_BACK, (uint32_t)cand, sc.tris, s.best, s.bestPrim);
+                            test_triangle(ta, tb, tc, s.r, RTX_HIT_FRONT_AND_BACK, (uint32_t)cand, sc.tris, s.best, s.bestPrim, s.bestWord);
                             if (s.best.slot >= 0 && shadow_hit_decides(scArg, s, maxDist, (useTransmittance & 1) != 0)) {
 #ifdef SHADOW_CACHE_STATS
                                 cacheHits++;
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
                         const bool withT = (useTransmittance & 1) != 0;
                         if (mode == 1) {
                             // a closer hit: another opaque surface changes nothing, one that lets light through ends the shortcut
-                            if ((sc.tris[s.best.slot].obj & TRI_OPAQUE) == 0u) {
+                            if ((s.bestWord & TRI_OPAQUE) == 0u) {
                                 mode = 3;
                                 stop = true;
                             }

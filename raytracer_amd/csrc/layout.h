@@ -80,11 +80,16 @@ struct TriRec {
     float e2x, e2y, e2z;
     uint32_t obj;           // object index (read for analytic and transformed records only) | TRI_OPAQUE: the object's material lets no
                             // light through (Visible() returns 0 at it). Kept out of `kind`, which the triangle test reads.
+                            // | TRI_INTERIOR: a world-space triangle that lies inside the root's box and its object's box by
+                            // twice the margin of well_inside_box (traverse.h) for any hit distance below 1000: the reference's
+                            // box tests cannot cull a hit on it, and the box-cull checks of the lean kernels need no box fetch
 };
 static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
 #define RTX_KIND_XFTRI 3u
-#define TRI_OBJ_MASK 0x7FFFFFFFu
+#define TRI_OBJ_MASK 0x3FFFFFFFu
 #define TRI_OPAQUE 0x80000000u
+#define TRI_INTERIOR 0x40000000u
+#define TRI_INTERIOR_TMAX 1000.0f
 
 struct TriAttr {
     float n0[3], n1[3], n2[3];

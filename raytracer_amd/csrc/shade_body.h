@@ -109,7 +109,7 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
                                            uint32_t slot, const RayT& ray, const HitT& h, int bounce, int maxBounces,
                                            unsigned long long seed, int sBase, int S, const int* __restrict__ pixels,
                                            const SegQ& qShadow, uint32_t neeIndex = 0u, const SegQ* qNee = nullptr,
-                                           const DevLight* lightsArg = nullptr, uint32_t ws = 0xFFFFFFFFu) {
+                                           const DevLight* lightsArg = nullptr, uint32_t ws = 0xFFFFFFFFu, bool* culledOut = nullptr) {
     if (ws == 0xFFFFFFFFu) ws = slot;
     // the lights, read where the kernel's argument holds them: shade_kernel shades with a copy of the scene descriptor whose
     // table pointers lead to LDS, and an array indexed at run time would keep that whole copy in scratch memory
@@ -144,6 +144,7 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
         const int pix = pixels[(cs / (uint32_t)S) * 64u + lane64];
         const int sIdx = sBase + (int)(cs % (uint32_t)S);
         bool pending = false;   // NEE of this bounce to be resolved
+        bool culled = false;    // the vertex is left to the general kernels (below): nothing is written
         uint32_t pendMask = sc.n_lights >= 32 ? 0xFFFFFFFFu : (1u << sc.n_lights) - 1u;   // lights whose nee records this vertex writes (resolve_add)
 
         do {
@@ -175,6 +176,23 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
             SurfHit sh;
             if (h.slot >= 0) resolve_triangle(sc, ray, h, sh);
             else resolve_light(lights, ray, h, sh);
+            // Lean kernels (shade_kernel of a scene of world-space triangles): a hit that the reference's box tests would have
+            // culled - not checked by the lean extend kernel - leaves the vertex alone; its path goes to the general tail kernel,
+            // which traces the ray again (rtx_render.cpp). Here, where the triangle record is at hand: a triangle well inside
+            // both boxes (TRI_INTERIOR, most of them) costs the check no memory access at all.
+            if (!TAIL && culledOut && pool.cullPaths && h.slot >= 0 && !ref_reaches_interior(sh.triWord, ray, h.t)) {
+                float ob[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) ob[i] = sc.objXf[sh.obj].box[i];
+                if (!ref_reaches_box<false>(sc, ray, ob, h.t)) {
+                    const uint32_t k = atomicAdd(&pool.totals[4], 1u);
+                    if (k < RTX_CULL_CAP) {
+                        pool.cullPaths[k] = slot;
+                        culled = true;
+                        break;
+                    }
+                }
+            }
             const float hitDist = len3(sh.p - rorg);
             if ((flags & PF_INSIDE_MEDIUM) && hitDist > 0.0f) beta = apply_absorption(beta, mediumAbs, hitDist);
 
@@ -402,6 +420,10 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
             alive = true;
         } while (false);
 
+        if (culled) {
+            *culledOut = true;
+            return false;
+        }
         pool.L[ws] = make_float4(L.x, L.y, L.z, L4.w);
         pool.beta[ws] = make_float4(beta.x, beta.y, beta.z, lastPdf);
         pool.medium[ws] = make_float4(mediumAbs.x, mediumAbs.y, mediumAbs.z, __uint_as_float(flags));

@@ -91,7 +91,7 @@ __device__ __forceinline__ bool shadow_hop_end(const SC& sc, f3& o, f3 d, float&
 __device__ __forceinline__ bool shadow_hit_decides(const DevScene& sc, const TravState& s, float maxDist, bool useTransmittance) {
     if (s.best.slot < 0) return false;
     if (!(s.best.t < (maxDist - 1e-4f) * 0.99999f)) return false;
-    if (useTransmittance && (sc.tris[s.best.slot].obj & TRI_OPAQUE) == 0u) return false;
+    if (useTransmittance && (s.bestWord & TRI_OPAQUE) == 0u) return false;   // (the record's word, kept from the triangle test)
     for (int i = 0; i < sc.n_lights; ++i) {
         const DevLight& L = sc.lights[i];
         if (L.size <= 0.0f) continue;

@@ -9,6 +9,7 @@ struct SurfHit {
     f3 p, N, GN, uvw, dpdu, dpdv;
     float t;
     int obj, mtlID, face, light;  // light = index or -1
+    uint32_t triWord;             // the triangle record's `obj` word (TRI_OPAQUE, TRI_INTERIOR); 0 for analytic objects and lights
     bool front;
 };
 
@@ -182,10 +183,12 @@ __device__ __forceinline__ void resolve_triangle(const DevScene& sc, const RayT&
     const float4 b = tris4[(size_t)h.slot * 3 + 1];
     const float4 c = tris4[(size_t)h.slot * 3 + 2];
     const uint32_t kind = __float_as_uint(b.w);
+    s.triWord = 0u;
     if (kind != 0u && kind != RTX_KIND_XFTRI) {
         resolve_analytic(sc, kind, __float_as_uint(c.w) & TRI_OBJ_MASK, r, h, s);
         return;
     }
+    s.triWord = __float_as_uint(c.w);
     // the ray in the triangle's own space: world for identity nodes, node coordinates otherwise (the HitInfo is then built
     // in object space as objects.cpp:172-240 does and brought back by Node::FromNodeCoords, IntersectNodeAdapter.h:93)
     RayT rr = r;
@@ -278,6 +281,7 @@ __device__ __forceinline__ void resolve_light(const DevLight* lights, const RayT
     s.face = -1;
     s.light = li;
     s.front = dot3(dir, s.N) <= 0.0f;
+    s.triWord = 0u;
     s.uvw = mk3(0.5f);
     s.dpdu = mk3(0.0f);
     s.dpdv = mk3(0.0f);

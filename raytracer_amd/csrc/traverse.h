@@ -134,9 +134,15 @@ __device__ __forceinline__ bool ref_reaches_box(const DevScene& sc, const RayT& 
     if (!ref_box_hit(sc.bounds, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.tmax)) return false;
     return ref_box_hit(obox, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.tmax);
 }
+// (word: the triangle record's `obj` word)
+__device__ __forceinline__ bool ref_reaches_interior(uint32_t word, const RayT& r, float t) {
+    return (word & TRI_INTERIOR) != 0u && t < TRI_INTERIOR_TMAX && r.tmax > t * 1.001f;   // implies `sure` of ref_reaches_box
+}
 template <bool OUTLINE>
 __device__ __forceinline__ bool ref_reaches_triangle(const DevScene& sc, const RayT& r, int slot, float t) {
-    const uint32_t obj = sc.tris[slot].obj & TRI_OBJ_MASK;
+    const uint32_t word = sc.tris[slot].obj;
+    if (ref_reaches_interior(word, r, t)) return true;   // no box to fetch: most triangles of most scenes
+    const uint32_t obj = word & TRI_OBJ_MASK;
     float ob[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) ob[i] = sc.objXf[obj].box[i];
@@ -145,8 +151,10 @@ __device__ __forceinline__ bool ref_reaches_triangle(const DevScene& sc, const R
 
 // One triangle, objects.cpp:140-171 and :190-191. The arithmetic order is the reference's; contraction is off so
 // that u, v and t are bit-identical to an fp32 CPU evaluation. r is the ray in the triangle's own space.
+// bestWord: the accepted record's `obj` word (TRI_OPAQUE, TRI_INTERIOR), already in a register here - the shadow kernel decides
+// with it what would otherwise be a dependent fetch per accepted hit and per hop end; kernels that never read it drop it.
 __device__ __forceinline__ void test_triangle(const float4 a, const float4 b, const float4 c, const RayT& r, int hitSide,
-                                              uint32_t slot, const TriRec* tris, HitT& best, uint32_t& bestPrim,
+                                              uint32_t slot, const TriRec* tris, HitT& best, uint32_t& bestPrim, uint32_t& bestWord,
                                               uint32_t excl = 0x7FFFFFFFu) {
 #pragma clang fp contract(off)
     const float e1x = b.x, e1y = b.y, e1z = b.z;
@@ -194,6 +202,7 @@ __device__ __forceinline__ void test_triangle(const float4 a, const float4 b, co
     best.v = v;
     best.slot = (int)slot;
     bestPrim = prim;
+    bestWord = __float_as_uint(c.w);
 }
 
 // Analytic objects (one record per object, TriRec::kind != 0): the ray goes to object space with the node's inverse
@@ -207,9 +216,10 @@ __device__ __forceinline__ void ray_to_object(const DevScene& sc, uint32_t obj, 
         d[k] = M[4 * k] * r.dx + M[4 * k + 1] * r.dy + M[4 * k + 2] * r.dz;
     }
 }
-__device__ __forceinline__ void test_analytic(const DevScene& sc, uint32_t kind, uint32_t obj, uint32_t prim, const RayT& r,
-                                              int hitSide, uint32_t slot, HitT& best, uint32_t& bestPrim) {
+__device__ __forceinline__ void test_analytic(const DevScene& sc, uint32_t kind, uint32_t word, uint32_t prim, const RayT& r,
+                                              int hitSide, uint32_t slot, HitT& best, uint32_t& bestPrim, uint32_t& bestWord) {
 #pragma clang fp contract(off)
+    const uint32_t obj = word & TRI_OBJ_MASK;
     float p[3], d[3];
     ray_to_object(sc, obj, r, p, d);
     if (!ref_box_hit(sc.objXf[obj].box, p[0], p[1], p[2], d[0], d[1], d[2], best.t)) return;   // [-1,1]^3, or the flat [-1,1]^2 x {0}
@@ -251,6 +261,7 @@ __device__ __forceinline__ void test_analytic(const DevScene& sc, uint32_t kind,
     best.v = 0.0f;
     best.slot = (int)slot;
     bestPrim = prim;
+    bestWord = word;
 }
 // Scene argument of the traversal functions with one compile-time fact attached: whether the scene holds meshes under a
 // non-identity node transform (RTX_KIND_XFTRI records). Their test is a second inlined copy of the triangle test behind
@@ -266,19 +277,19 @@ struct DevSceneT : DevScene {
 };
 template <class SC>
 __device__ __forceinline__ void test_primitive(const SC& sc, const float4 a, const float4 b, const float4 c, const RayT& r,
-                                               int hitSide, uint32_t slot, HitT& best, uint32_t& bestPrim, uint32_t excl) {
+                                               int hitSide, uint32_t slot, HitT& best, uint32_t& bestPrim, uint32_t& bestWord, uint32_t excl) {
     const uint32_t kind = __float_as_uint(b.w);
     if (!SC::kXF) excl = 0x7FFFFFFFu;   // (a constant there: the compare in test_triangle can never hold and goes away)
-    if (kind == 0u) test_triangle(a, b, c, r, hitSide, slot, sc.tris, best, bestPrim, excl);
+    if (kind == 0u) test_triangle(a, b, c, r, hitSide, slot, sc.tris, best, bestPrim, bestWord, excl);
     else if (!SC::kXF) return;   // identity meshes only (DevScene::has_xf == 0): no other kind of record exists
     else if (kind == RTX_KIND_XFTRI) {
         // a mesh under a non-identity node transform: the ray goes to node coordinates (direction not renormalised, so t
         // is the same parameter) and meets the object's own fp32 vertices (IntersectNodeAdapter.h:62 -> objects.cpp:140)
         float p[3], d[3];
         ray_to_object(sc, __float_as_uint(c.w) & TRI_OBJ_MASK, r, p, d);
-        test_triangle(a, b, c, RayT{p[0], p[1], p[2], d[0], d[1], d[2], r.tmax}, hitSide, slot, sc.tris, best, bestPrim, excl);
+        test_triangle(a, b, c, RayT{p[0], p[1], p[2], d[0], d[1], d[2], r.tmax}, hitSide, slot, sc.tris, best, bestPrim, bestWord, excl);
     } else
-        test_analytic(sc, kind, __float_as_uint(c.w) & TRI_OBJ_MASK, __float_as_uint(a.w), r, hitSide, slot, best, bestPrim);
+        test_analytic(sc, kind, __float_as_uint(c.w), __float_as_uint(a.w), r, hitSide, slot, best, bestPrim, bestWord);
 }
 
 // ---- traversal as a small state machine -------------------------------------------------------------------
@@ -294,6 +305,7 @@ struct TravState {
     float idx, idy, idz;     // 1 / dir (IEEE: +-inf for axis-parallel rays)
     HitT best;
     uint32_t bestPrim;
+    uint32_t bestWord;       // TriRec::obj of the best hit (0 while there is none)
     uint32_t cur;
     int sp;
     uint32_t excl;           // general kernels: object left out of this traversal (its box culled it for this ray: trav_verify)
@@ -310,6 +322,7 @@ __device__ __forceinline__ void trav_init(TravState& s, const DevScene& sc, cons
     s.best.v = 0.0f;
     s.best.slot = -1;
     s.bestPrim = 0xFFFFFFFFu;
+    s.bestWord = 0u;
     s.cur = sc.root;        // RTX_EMPTY_CHILD for an empty scene == DONE
     s.sp = 0;
     s.excl = RTX_NO_OBJECT;
@@ -445,7 +458,7 @@ __device__ __forceinline__ uint32_t trav_leaf_test(TravState& s, const SC& sc, u
         const float4 a = tris4[(size_t)slot * 3 + 0];
         const float4 b = tris4[(size_t)slot * 3 + 1];
         const float4 c = tris4[(size_t)slot * 3 + 2];
-        test_primitive(sc, a, b, c, s.r, hitSide, slot, s.best, s.bestPrim, s.excl);
+        test_primitive(sc, a, b, c, s.r, hitSide, slot, s.best, s.bestPrim, s.bestWord, s.excl);
     }
     return cnt;
 }
@@ -482,6 +495,7 @@ __device__ __forceinline__ bool trav_verify(TravState& s, const SC& sc) {
         s.best.v = 0.0f;
         s.best.slot = -1;
         s.bestPrim = 0xFFFFFFFFu;
+        s.bestWord = 0u;
         return true;
     }
     if (kind != 0u && kind != RTX_KIND_XFTRI) return true;   // Sphere / Plane: tested on the way in (test_analytic)
