@@ -61,13 +61,24 @@ __device__ __forceinline__ bool resolve_add(const PathPool& pool, uint32_t slot,
     const f3 beta = mk3(pb.x, pb.y, pb.z);
     f3 direct = mk3(0.0f);
     float maxVisibility = 0.0f;
-    for (int l = 0; l < nLights; ++l) {
-        if (((lights >> l) & 1u) == 0u) continue;
-        const float4 c = pool.nee[(size_t)l * pool.capacity + slot];
-        if (c.w < 0.0f) continue;
-        maxVisibility = fmaxf(maxVisibility, c.w);
-        if (c.w <= 0.0f) continue;
-        direct = direct + mk3(c.x, c.y, c.z) * c.w;
+    // (four lights' records are fetched together, then added in light order: one memory round trip for the usual scene instead
+    // of one per light)
+    for (int l0 = 0; l0 < nLights; l0 += 4) {
+        float4 c4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int l = l0 + k;
+            c4[k] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+            if (l < nLights && ((lights >> l) & 1u) != 0u) c4[k] = pool.nee[(size_t)l * pool.capacity + slot];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 c = c4[k];
+            if (c.w < 0.0f) continue;
+            maxVisibility = fmaxf(maxVisibility, c.w);
+            if (c.w <= 0.0f) continue;
+            direct = direct + mk3(c.x, c.y, c.z) * c.w;
+        }
     }
     if (max3c(direct) > 0.0f) L = L + beta * direct;
     if (usePhotons) {
