@@ -222,8 +222,11 @@ void launch_unpack(const PathPool& pool, uint32_t nUsed, int nLights, int usePho
 #ifndef SHADOW_ANYHIT
 #define SHADOW_ANYHIT 1
 #endif
+// lanes that have ended a hop or hold no segment before the wave resolves / refills them: a shadow hop's end costs more than a
+// closest-hit ray's (light spheres, the chain's next hop, the box-cull check) and is worth waiting for more lanes than the
+// extend kernel's 16 - shadow per C3 frame at 8 / 16 / 24 / 32 / 40 / 48: 180 / 171 / 169 / 167 / 171 / 177 ms
 #ifndef SHADOW_REFILL_MIN
-#define SHADOW_REFILL_MIN 16
+#define SHADOW_REFILL_MIN 32
 #endif
 // useTransmittance: bit 0 = Visible() with transmittance (else VisibleSimple), bit 1 = no early exit (parity checks)
 // CULL (lean kernel only): hops that end on a hit are checked against the reference's box tests (PathPool::cullShadows)

@@ -1,6 +1,7 @@
 // HIP kernels for ray casting on gfx950: extend (closest hit), pixel-centre ray generation, hit expansion and
 // the shadow-chain visibility query. See traverse.h / shadow.h for the device functions and their reference
 // citations.
+#define RTX_TRAV_FAST_RCP 1   // traverse.h trav_init: 1 / dir by v_rcp_f32 in this translation unit (extend_kernel, visibility_kernel)
 #include "kernels.h"
 #include "shadow.h"
 #include "segqueue.h"

@@ -314,9 +314,19 @@ struct TravState {
 
 __device__ __forceinline__ void trav_init(TravState& s, const DevScene& sc, const RayT& r) {
     s.r = r;
+    // 1 / dir serves the slab tests alone - a box is entered with a margin of 1e-5 (RTX_CULL_SLACK), hits are decided by the
+    // triangle test, which does not read it - so the hardware reciprocal (1 ulp; +-0 -> +-inf) can stand in for three IEEE
+    // divisions. kernels_trace.hip asks for it (extend -1.5 ms per C3 frame); the shadow kernel sits on a register cliff where
+    // the other instruction sequence costs it 16 more spilled registers (171 -> 200 ms), so it is not the default.
+#ifdef RTX_TRAV_FAST_RCP
+    s.idx = __builtin_amdgcn_rcpf(r.dx);
+    s.idy = __builtin_amdgcn_rcpf(r.dy);
+    s.idz = __builtin_amdgcn_rcpf(r.dz);
+#else
     s.idx = 1.0f / r.dx;
     s.idy = 1.0f / r.dy;
     s.idz = 1.0f / r.dz;
+#endif
     s.best.t = r.tmax;      // HitInfo::z in-out upper bound (IntersectNodeAdapter.h:28)
     s.best.u = 0.0f;
     s.best.v = 0.0f;
