@@ -51,6 +51,11 @@ __device__ __forceinline__ unsigned long long rng_key(unsigned long long seed, u
     return mix64(seed ^ (((unsigned long long)a << 32) | (unsigned long long)b));
 }
 __device__ __forceinline__ float rng_draw(unsigned long long key, uint32_t stream, uint32_t dim) {
+#ifdef RTX_ABLATE_RNG   // (timing-only variant: a 32-bit hash with two multiplies; wrong images)
+    uint32_t h = (uint32_t)key ^ (uint32_t)(key >> 32) ^ (stream * 0x9e3779b9u + dim * 0x85ebca6bu);
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+#endif
     const unsigned long long k2 =
         mix64(key + (((unsigned long long)stream << 32) | (unsigned long long)dim) * 0x9e3779b97f4a7c15ULL + 0x9e3779b97f4a7c15ULL);
     return (float)(k2 >> 40) * (1.0f / 16777216.0f);
