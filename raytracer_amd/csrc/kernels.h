@@ -65,7 +65,7 @@ uint32_t launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& 
 void launch_unpack(const PathPool& pool, uint32_t nUsed, int nLights, int usePhotons, hipStream_t stream);
 // the (vertex, light) pairs that shade launch (n vertices) has queued in pool.qN, one lane per pair: lobe evaluation, MIS
 // weight, shadow segments appended to qShadow (kernels_nee.hip). The queue must have been scanned; returns the grid size.
-uint32_t launch_nee(const DevScene& sc, const PathPool& pool, uint32_t n, const SegQ& qShadow, int materialKinds, hipStream_t stream);
+uint32_t launch_nee(const DevScene& sc, const PathPool& pool, uint32_t n, const SegQ& qShadow, int materialKinds, hipStream_t stream, uint32_t pairs = 0u);
 // the rest of a pass for its last n paths in one kernel (n <= RTX_TAIL_MAX_PATHS)
 #ifndef RTX_TAIL_MAX_PATHS
 #define RTX_TAIL_MAX_PATHS 65536u

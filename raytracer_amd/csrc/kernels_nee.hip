@@ -26,8 +26,9 @@
 #ifndef NEE_WAVES_PER_EU
 #define NEE_WAVES_PER_EU 4
 #endif
-// nBound: an upper bound of the queue's entries (the host sizes the grid by vertices x lights without reading the count
-// back); blocks beyond the true total leave at once.
+// nBound: the queue's entries, or an upper bound of them (vertices x lights when the caller does not know the count: blocks
+// beyond the true total leave at once - at a price, 7 ms per C3 frame for three empty blocks in four: rtx_render.cpp reads the
+// count back).
 template <bool MICRO, bool PHONG>
 __global__ __launch_bounds__(NEE_BLOCK) __attribute__((amdgpu_waves_per_eu(NEE_WAVES_PER_EU))) void nee_kernel(DevScene sc, PathPool pool, SegQ qIn, uint32_t nBound, SegQ qShadow) {
     __shared__ uint32_t qtab[SEGQ_TABLE_WORDS];
@@ -97,9 +98,9 @@ __global__ __launch_bounds__(NEE_BLOCK) __attribute__((amdgpu_waves_per_eu(NEE_W
 
 // The pairs the shade launch over n vertices has just queued in pool.qN (scanned). Returns the grid size: the geometry the
 // scan of the shadow queue needs (one entry per thread at most).
-uint32_t launch_nee(const DevScene& sc, const PathPool& pool, uint32_t n, const SegQ& qShadow, int materialKinds, hipStream_t stream) {
+uint32_t launch_nee(const DevScene& sc, const PathPool& pool, uint32_t n, const SegQ& qShadow, int materialKinds, hipStream_t stream, uint32_t pairs) {
     if (!n || sc.n_lights <= 0) return 0;
-    const unsigned long long bound = (unsigned long long)n * (unsigned long long)sc.n_lights;
+    const unsigned long long bound = pairs ? (unsigned long long)pairs : (unsigned long long)n * (unsigned long long)sc.n_lights;
     const uint32_t nBound = (uint32_t)(bound > 0xFFFFFF00ull ? 0xFFFFFF00ull : bound);   // (the pool holds fewer than 2^32 shadow segments: rtx_render.cpp)
     const uint32_t grid = (nBound + NEE_BLOCK - 1) / NEE_BLOCK;
 #define RTX_LAUNCH_NEE(M, G) hipLaunchKernelGGL((nee_kernel<M, G>), dim3(grid), dim3(NEE_BLOCK), 0, stream, sc, pool, pool.qN, nBound, qShadow)

@@ -499,8 +499,17 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                                                         curPixels, sqOut, qout, pool.qS, shadeKinds, st, repackBase);
                 tm.end(st);
                 launch_segq_scan2(sqOut, gridShade, 1, pool.qN, gridShade, shadowMult, 256, pool.totals, st);   // totals[0] paths alive, [1] pairs
+                // The number of pairs, read back for the nee grid: sized by its upper bound (vertices x lights, three quarters of it
+                // blocks that find nothing and leave) the launch costs 7 ms more per C3 frame than this second round trip per bounce.
+                uint32_t neeBound = 0;
+                {
+                    uint32_t pc[2] = {0, 0};
+                    RTX_HIP(hipMemcpyAsync(pc, pool.totals, sizeof(pc), hipMemcpyDeviceToHost, st));
+                    RTX_HIP(hipStreamSynchronize(st));
+                    neeBound = pc[1] ? pc[1] : 1u;
+                }
                 tm.begin(3, st);
-                const uint32_t gridNee = launch_nee(s->dev, pool, n, pool.qS, shadeKinds, st);
+                const uint32_t gridNee = launch_nee(s->dev, pool, n, pool.qS, shadeKinds, st, neeBound);
                 tm.end(st);
                 out.shade_launches++;
                 out.vertices += n;
