@@ -312,7 +312,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
                 if (mode != 3) {
                     intersect_lights(scArg, s.r, s.best);
                     float T;
-                    if (shadow_hop_end(sc, o, d, maxDist, s.best, (useTransmittance & 1) != 0, hop, visibility, T)) {
+                    if (shadow_hop_end(sc, o, d, maxDist, s.best, (useTransmittance & 1) != 0, hop, visibility, T, s.bestWord)) {
                         pool.nee[(size_t)(code & 7u) * pool.capacity + (code >> 3)].w = T;
                         s.cur = RTX_LANE_IDLE;
                         next = false;

@@ -36,9 +36,12 @@ __device__ __forceinline__ void triangle_gn(const SC& sc, const RayT& r, int slo
 // End of one hop of the chain (RayCaster.cpp:205-276): h is the closest hit of the segment (o, d, maxDist), lights
 // included. Returns true when the chain ends (value in `result`), false when the next hop starts from the updated
 // (o, maxDist) with the updated running visibility.
+// word: the hit record's `obj` word when the caller has kept it from the triangle test (TravState::bestWord), else 0. TRI_OPAQUE
+// in it is the builder's statement of the two conditions below that end the chain with 0 - no material, or max(kt) <= 0
+// (bvh_build.cpp emit_tri) - and saves the three dependent fetches (triangle, object, material) that would find them out again.
 template <class SC>
 __device__ __forceinline__ bool shadow_hop_end(const SC& sc, f3& o, f3 d, float& maxDist, const HitT& h, bool useTransmittance,
-                                               int& hop, float& visibility, float& result) {
+                                               int& hop, float& visibility, float& result, uint32_t word = 0u) {
     result = visibility;
     if (h.slot == -1) return true;   // nothing blocking
     if (h.slot <= -2) return true;   // hit the light itself
@@ -52,6 +55,7 @@ __device__ __forceinline__ bool shadow_hop_end(const SC& sc, f3& o, f3 d, float&
     if (dist >= maxDist - 1e-4f) return true;
     result = 0.0f;
     if (!useTransmittance) return true;    // VisibleSimple :189
+    if ((word & TRI_OPAQUE) != 0u) return true;
     f3 GN;
     bool front;
     int obj;
