@@ -37,10 +37,15 @@ struct TravStack {
         // deeper than STACK_LDS+STACK_GLOBAL cannot happen: host rejects BVHs with 3*depth+1 above the budget
         ++sp;
     }
+    // (the LDS entry is read whatever the depth, at a clamped index: written as "LDS or slab" the two loads become ONE flat load
+    // through a selected generic pointer - every pop then goes the flat path and waits for the vector-memory and the LDS counters)
     __device__ __forceinline__ uint2 pop(int& sp) {
         --sp;
-        if (sp < STACK_LDS) return lds[sp * TRAV_BLOCK];
-        return spill[(size_t)(sp - STACK_LDS) * stride];
+        typedef __attribute__((address_space(3))) const unsigned long long* LdsPtr;   // (an LDS pointer by type: it cannot be merged with the slab's)
+        const unsigned long long w = ((LdsPtr)lds)[(sp < STACK_LDS ? sp : STACK_LDS - 1) * TRAV_BLOCK];
+        uint2 e = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+        if (sp >= STACK_LDS) e = spill[(size_t)(sp - STACK_LDS) * stride];
+        return e;
     }
 };
 
