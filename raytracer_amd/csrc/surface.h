@@ -46,9 +46,14 @@ __device__ __forceinline__ TexTap tex_tap(int w, int h, f3 uvw) {
     t.i11 = (size_t)iyp * w + ixp;
     return t;
 }
-__device__ __forceinline__ f3 tex_unorm(uchar4 c) {
-    return mk3(rtx_unorm8((float)c.x), rtx_unorm8((float)c.y), rtx_unorm8((float)c.z));   // = (float)c.x / 255.0f ... bit for bit
+__device__ __forceinline__ f3 tex_unorm(uint32_t c) {   // RGBA8 texel, r in the low byte
+    return mk3(rtx_unorm8((float)(c & 0xFFu)), rtx_unorm8((float)((c >> 8) & 0xFFu)), rtx_unorm8((float)((c >> 16) & 0xFFu)));   // = (float)c.x / 255.0f ... bit for bit
 }
+// Texel pointers by address space: the map descriptors reach the shade kernel through a table in LDS, so the compiler cannot see
+// that `texels` points to global memory and would issue flat loads (which take the LDS and the vector-memory path both).
+typedef float rtx_f4n __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const uint32_t* TexelPtr8;
+typedef __attribute__((address_space(1))) const rtx_f4n* TexelPtrF;
 __device__ __forceinline__ f3 tex_blend(const TexTap& t, f3 c00, f3 c10, f3 c01, f3 c11) {
     return c00 * ((1 - t.fx) * (1 - t.fy)) + c10 * (t.fx * (1 - t.fy)) + c01 * ((1 - t.fx) * t.fy) + c11 * (t.fx * t.fy);
 }
@@ -65,8 +70,8 @@ __device__ __forceinline__ void tex_eval_raw_n(const DevTexMap& tm, const f3 (&u
 #pragma unroll
     for (int k = 0; k < N; ++k) t[k] = tex_tap(w, h, uvw[k]);
     if (tm.format == RTX_TEX_RGB8) {
-        const uchar4* tx = reinterpret_cast<const uchar4*>(tm.texels);
-        uchar4 c[N][4];
+        const TexelPtr8 tx = (TexelPtr8)tm.texels;
+        uint32_t c[N][4];
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             c[k][0] = tx[t[k].i00];
@@ -77,10 +82,10 @@ __device__ __forceinline__ void tex_eval_raw_n(const DevTexMap& tm, const f3 (&u
 #pragma unroll
         for (int k = 0; k < N; ++k) out[k] = tex_blend(t[k], tex_unorm(c[k][0]), tex_unorm(c[k][1]), tex_unorm(c[k][2]), tex_unorm(c[k][3]));
     } else {
-        const float4* tx = reinterpret_cast<const float4*>(tm.texels);
+        const TexelPtrF tx = (TexelPtrF)tm.texels;
 #pragma unroll
         for (int k = 0; k < N; ++k) {   // (16-byte texels: one tap's loads at a time, or three taps would hold 48 registers)
-            const float4 c00 = tx[t[k].i00], c10 = tx[t[k].i10], c01 = tx[t[k].i01], c11 = tx[t[k].i11];
+            const rtx_f4n c00 = tx[t[k].i00], c10 = tx[t[k].i10], c01 = tx[t[k].i01], c11 = tx[t[k].i11];
             out[k] = tex_blend(t[k], mk3(c00.x, c00.y, c00.z), mk3(c10.x, c10.y, c10.z), mk3(c01.x, c01.y, c01.z), mk3(c11.x, c11.y, c11.z));
         }
     }
