@@ -32,7 +32,8 @@ struct TravStack {
     uint32_t stride;     // total threads of the grid
     __device__ __forceinline__ void push(int& sp, uint32_t ref, float t) {
         uint2 e = make_uint2(ref, __float_as_uint(t));
-        if (sp < STACK_LDS) lds[sp * TRAV_BLOCK] = e;
+        typedef __attribute__((address_space(3))) unsigned long long* LdsPtrW;   // (LDS by type, as in pop: no flat store through a selected pointer)
+        if (sp < STACK_LDS) ((LdsPtrW)lds)[sp * TRAV_BLOCK] = (unsigned long long)e.x | ((unsigned long long)e.y << 32);
         else if (sp < STACK_LDS + STACK_GLOBAL) spill[(size_t)(sp - STACK_LDS) * stride] = e;
         // deeper than STACK_LDS+STACK_GLOBAL cannot happen: host rejects BVHs with 3*depth+1 above the budget
         ++sp;
