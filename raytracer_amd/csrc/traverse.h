@@ -333,6 +333,13 @@ __device__ __forceinline__ void trav_init(TravState& s, const DevScene& sc, cons
     s.idy = 1.0f / r.dy;
     s.idz = 1.0f / r.dz;
 #endif
+    // ... and kept finite: an axis-parallel ray (1/0 = +-inf) is as parallel at +-2^60, and the slab test can then form a plane's
+    // distance with ONE fused multiply-add, q * (scale/dir) + (origin - ro)/dir, without meeting inf - inf (trav_inner_step)
+#ifndef RTX_TRAV_SLAB_TWO_OPS
+    s.idx = __builtin_amdgcn_fmed3f(s.idx, -0x1p60f, 0x1p60f);
+    s.idy = __builtin_amdgcn_fmed3f(s.idy, -0x1p60f, 0x1p60f);
+    s.idz = __builtin_amdgcn_fmed3f(s.idz, -0x1p60f, 0x1p60f);
+#endif
     s.best.t = r.tmax;      // HitInfo::z in-out upper bound (IntersectNodeAdapter.h:28)
     s.best.u = 0.0f;
     s.best.v = 0.0f;
@@ -386,15 +393,16 @@ __device__ __forceinline__ void trav_skip_opaque(TravState& s, TravStack& st) {
     s.cur = next;
 }
 
-// One inner node (64 B = 4 x dwordx4). The slab test runs in the node's quantised frame: with scale = 2^e exact,
-// t = (q - (ro - o)/scale) * (scale/dir), and the near/far planes of an axis go through one packed subtract and one
-// packed multiply (v_pk_add_f32 / v_pk_mul_f32). Which plane is the near one follows from the sign of the direction,
-// so the near/far bytes of all four children are picked with one select per axis before they are converted (byte ->
-// float is a single v_cvt_f32_ubyteN). Axis-parallel rays (1/dir = +-inf) give +-inf on the right side of the
-// comparison; the NaN of 0 * inf (origin exactly on a plane) is dropped by fminf/fmaxf, which only makes the test
-// more conservative. The far side is widened (RTX_CULL_SLACK) so rounding never culls a box the ray grazes (the reference's
-// scene_box.cpp:8-46 accepts tmin <= tmax inclusively as well). [An FMA form q*k + c turns axis-parallel rays into
-// inf - inf = NaN on every plane: such rays then visit the whole tree.]
+// One inner node (64 B = 4 x dwordx4). The slab test works on the quantised planes directly: with scale = 2^e exact, the
+// distance to plane q of an axis is q * (scale/dir) + (o - ro)/dir - one fused multiply-add per plane, two planes per
+// v_pk_fma_f32 (round 3; before: a packed subtract and a packed multiply in the node's quantised frame). Which plane is the
+// near one follows from the sign of the direction, so the near/far bytes of all four children are picked with one select per
+// axis before they are converted (byte -> float is a single v_cvt_f32_ubyteN). 1/dir is kept finite (trav_init: +-2^60 for an
+// axis-parallel ray), so no inf - inf arises [with 1/dir = +-inf the fused form is NaN on every plane of such a ray, NaNs
+// are dropped by fminf/fmaxf, and the ray visits the whole tree: 5.4 s for a handful of zero-length directions,
+// tests/test_closest_hit_gpu.py::test_degenerate_directions]; a remaining NaN (NaN inputs are turned away by trav_init) only
+// makes the test more conservative. The far side is widened (RTX_CULL_SLACK) so rounding never culls a box the ray grazes
+// (the reference's scene_box.cpp:8-46 accepts tmin <= tmax inclusively as well).
 typedef float rtx_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void trav_inner_step(TravState& s, const DevScene& sc, TravStack& st) {
     const uint4* nodes4 = reinterpret_cast<const uint4*>(sc.nodes);
@@ -404,11 +412,21 @@ __device__ __forceinline__ void trav_inner_step(TravState& s, const DevScene& sc
     const uint4 w2 = nodes4[node * 4 + 2];  // qlo x[4] y[4] z[4] | qhi x[4]
     const uint4 w3 = nodes4[node * 4 + 3];  // qhi y[4] z[4] | pad
     const uint32_t ex = w0.w & 0xFFu, ey = (w0.w >> 8) & 0xFFu, ez = (w0.w >> 16) & 0xFFu;
-    // direction reciprocal per quantised unit and ray origin in quantised units (exact power-of-two scalings)
+    // distance to plane q of an axis: (o + q * scale - ro) / dir = q * (scale/dir) + (o - ro)/dir, one fused multiply-add per
+    // plane (two planes per v_pk_fma_f32); scale is a power of two, so scale/dir is exact, and 1/dir is finite (trav_init)
+    // (RTX_TRAV_SLAB_TWO_OPS: the earlier form, (q - (ro - o)/scale) * (scale/dir), a packed subtract and a packed multiply per
+    // pair of planes - kept for kernels_legacy.hip, where the other instruction mix moves a register spill in front of a lane
+    // re-enable: tools/check_spill_exec.py, DESIGN.md "Toolchain notes")
     const float qdx = s.idx * scale_from_exp(ex), qdy = s.idy * scale_from_exp(ey), qdz = s.idz * scale_from_exp(ez);
+#ifdef RTX_TRAV_SLAB_TWO_OPS
     const float rox = (s.r.ox - __uint_as_float(w0.x)) * __uint_as_float((254u - ex) << 23);
     const float roy = (s.r.oy - __uint_as_float(w0.y)) * __uint_as_float((254u - ey) << 23);
     const float roz = (s.r.oz - __uint_as_float(w0.z)) * __uint_as_float((254u - ez) << 23);
+#else
+    const float rox = (__uint_as_float(w0.x) - s.r.ox) * s.idx;
+    const float roy = (__uint_as_float(w0.y) - s.r.oy) * s.idy;
+    const float roz = (__uint_as_float(w0.z) - s.r.oz) * s.idz;
+#endif
     // sign bit of 1/dir (also right for -0 -> -inf): negative direction enters through the high plane
     const bool negx = (__float_as_uint(s.idx) >> 31) != 0u, negy = (__float_as_uint(s.idy) >> 31) != 0u,
                negz = (__float_as_uint(s.idz) >> 31) != 0u;
@@ -425,9 +443,15 @@ __device__ __forceinline__ void trav_inner_step(TravState& s, const DevScene& sc
         const rtx_f2 qx = {(float)((nqx >> sh) & 0xFFu), (float)((fqx >> sh) & 0xFFu)};
         const rtx_f2 qy = {(float)((nqy >> sh) & 0xFFu), (float)((fqy >> sh) & 0xFFu)};
         const rtx_f2 qz = {(float)((nqz >> sh) & 0xFFu), (float)((fqz >> sh) & 0xFFu)};
+#ifdef RTX_TRAV_SLAB_TWO_OPS
         const rtx_f2 tx = (qx - vrx) * vdx;
         const rtx_f2 ty = (qy - vry) * vdy;
         const rtx_f2 tz = (qz - vrz) * vdz;
+#else
+        const rtx_f2 tx = __builtin_elementwise_fma(qx, vdx, vrx);
+        const rtx_f2 ty = __builtin_elementwise_fma(qy, vdy, vry);
+        const rtx_f2 tz = __builtin_elementwise_fma(qz, vdz, vrz);
+#endif
         const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, 0.0f));
         const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, s.best.t));
         const bool hit = (cr[i] != RTX_EMPTY_CHILD) && (tn <= tf * RTX_CULL_SLACK);
