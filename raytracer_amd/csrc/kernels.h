@@ -56,6 +56,9 @@ struct DevPhotonMap;
 // initGuides: raygen also clears the first-hit guides and the pending-resolve marker (legacy mode; the path loop's first shade writes them)
 uint32_t launch_raygen(const DevCamera& cam, const PathPool& pool, const int* pixels, uint32_t nPix, int S, int sBase, int indexStride,
                        const SegQ& qOut, uint32_t* queueOut, int initGuides, hipStream_t stream);
+#ifndef RTX_SHADE_BLOCK
+#define RTX_SHADE_BLOCK 256   // threads per block of shade_kernel (its queue regions are laid out by it: rtx_render.cpp)
+#endif
 uint32_t launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pm, const SegQ& qIn,
                       const uint32_t* queueIn, uint32_t n, int bounce, int maxBounces, unsigned long long seed, int sBase, int S,
                       const int* pixels, const SegQ& qOut, uint32_t* queueOut, const SegQ& qShadow, int materialKinds,

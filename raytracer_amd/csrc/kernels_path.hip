@@ -141,7 +141,7 @@ __device__ __forceinline__ void shade_copy_table(T* dst, const T* src, int count
 // REPACK: this bounce moves the paths together (pathstate.h "Compaction"): the vertex at queue position i is read at its slot and
 // written to slot wbase + i of the compaction area, where the path lives from here on.
 template <bool MICRO, bool PHOT, bool PHONG, bool LDSTAB, bool REPACK = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MICRO || PHOT || PHONG) ? SHADE_WAVES_PER_EU_GENERAL : SHADE_WAVES_PER_EU))) void shade_kernel(DevScene scArg, DevCamera cam, PathPool pool, DevPhotonMap pm,
+__global__ __launch_bounds__(RTX_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu((MICRO || PHOT || PHONG) ? SHADE_WAVES_PER_EU_GENERAL : SHADE_WAVES_PER_EU))) void shade_kernel(DevScene scArg, DevCamera cam, PathPool pool, DevPhotonMap pm,
                                                     SegQ qIn, const uint32_t* __restrict__ queueIn, uint32_t n, int bounce,
                                                     int maxBounces, unsigned long long seed, int sBase, int S,
                                                     const int* __restrict__ pixels, SegQ qOut, uint32_t* __restrict__ queueOut,
@@ -651,10 +651,10 @@ uint32_t launch_shade(const DevScene& sc, const DevCamera& cam, const PathPool& 
                       const int* pixels, const SegQ& qOut, uint32_t* queueOut, const SegQ& qShadow, int materialKinds,
                       hipStream_t stream, uint32_t repackBase) {
     if (!n) return 0;
-    const uint32_t grid = (n + 255) / 256;
+    const uint32_t grid = (n + RTX_SHADE_BLOCK - 1) / RTX_SHADE_BLOCK;
     const bool ldsTab = sc.n_objs <= SHADE_LDS_OBJS && sc.n_mtls <= SHADE_LDS_MTLS && sc.n_texmaps <= SHADE_LDS_TEX;
 #define RTX_LAUNCH_SHADE_R(M, P, G, T, R)                                                                                            \
-    hipLaunchKernelGGL((shade_kernel<M, P, G, T, R>), dim3(grid), dim3(256), 0, stream, sc, cam, pool, pm, qIn, queueIn, n, bounce, maxBounces, \
+    hipLaunchKernelGGL((shade_kernel<M, P, G, T, R>), dim3(grid), dim3(RTX_SHADE_BLOCK), 0, stream, sc, cam, pool, pm, qIn, queueIn, n, bounce, maxBounces, \
                        seed, sBase, S, pixels, qOut, queueOut, qShadow, pool.qN, repackBase)
 #define RTX_LAUNCH_SHADE(M, P, G)                                                                                                    \
     if (ldsTab) {                                                                                                                    \

@@ -498,7 +498,7 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                 const uint32_t gridShade = launch_shade(s->dev, dc, pool, pm, sqIn, qin, n, bounce, rp->max_bounces, rp->seed, sBase, Sp,
                                                         curPixels, sqOut, qout, pool.qS, shadeKinds, st, repackBase);
                 tm.end(st);
-                launch_segq_scan2(sqOut, gridShade, 1, pool.qN, gridShade, shadowMult, 256, pool.totals, st);   // totals[0] paths alive, [1] pairs
+                launch_segq_scan2(sqOut, gridShade, 1, pool.qN, gridShade, shadowMult, RTX_SHADE_BLOCK, pool.totals, st);   // totals[0] paths alive, [1] pairs
                 // The number of pairs, read back for the nee grid: sized by its upper bound (vertices x lights, three quarters of it
                 // blocks that find nothing and leave) the launch costs 7 ms more per C3 frame than this second round trip per bounce.
                 uint32_t neeBound = 0;
