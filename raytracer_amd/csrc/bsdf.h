@@ -65,19 +65,11 @@ struct PhongCtx {
 // Shading.cpp:227-278 — built ONCE per hit (the reference rebuilds it for every GenerateSample/GetSampleInfo call)
 // SPECTEX = false: no material of the scene puts a texture on Specular / Reflection / Refraction / Glossiness (a scene fact,
 // rtx_scene::generalMtl): the four inlined texture fetches are then not compiled in
-template <bool SPECTEX = true>
-__device__ __forceinline__ PhongCtx build_phong_ctx(const DevScene& sc, const DevMaterial& m, const SampCtx& s) {
-    PhongCtx c;
-    c.N = normalized3(s.N);
-    if (!s.front) c.N = -c.N;
-    c.V = safe_normalize3(s.V);
-    c.R = safe_normalize3(reflect3(-c.V, c.N));
-    c.kd = eval_tc(sc, m.kd, m.kd_tex, s.uvw);
-    c.ks = eval_tc(sc, m.ks, SPECTEX ? m.ks_tex : -1, s.uvw);
-    c.kr = eval_tc(sc, m.kr, SPECTEX ? m.kr_tex : -1, s.uvw);
-    c.kt = eval_tc(sc, m.kt, SPECTEX ? m.kt_tex : -1, s.uvw);
-    c.alpha = fmaxf(0.001f, eval_tf(sc, m.gloss, SPECTEX ? m.gloss_tex : -1, s.uvw));
-    c.ior = m.ior;
+// The lobe terms of a context from its raw inputs - c.kd / ks / kr / kt / alpha / ior as Diffuse() ... Glossiness() evaluate, c.N and
+// c.V set - by the arithmetic of Shading.cpp:241-278. Apart from build_phong_ctx, nee_kernel runs it to rebuild the terms of a
+// vertex whose material holds no texture from the material record (nee_ctx.h, compact records): the same operations on the same
+// operands, hence the same bits.
+__device__ __forceinline__ void finish_phong_ctx(PhongCtx& c, bool front) {
     c.kd = clamp_max3(c.kd, 1.0f);
     c.ks = clamp_max3(c.ks, 1.0f);
     c.kr = clamp_max3(c.kr, 1.0f);
@@ -94,8 +86,8 @@ __device__ __forceinline__ PhongCtx build_phong_ctx(const DevScene& sc, const De
         c.kd = c.kd * scale;
         c.ks = c.ks * scale;
     }
-    const float etaI = s.front ? 1.0f : c.ior;
-    const float etaT = s.front ? c.ior : 1.0f;
+    const float etaI = front ? 1.0f : c.ior;
+    const float etaT = front ? c.ior : 1.0f;
     const float F = (c.ior > 0.0f && max3c(c.kt) > 0.0f) ? fresnel_dielectric(fabsf(dot3(c.N, c.V)), etaI, etaT) : 0.0f;
     c.fresnelRef = c.kt * F;
     c.transColor = c.kt * (1.0f - F);
@@ -104,7 +96,27 @@ __device__ __forceinline__ PhongCtx build_phong_ctx(const DevScene& sc, const De
     c.specColor = clamp_max3(c.specColor, 1.0f);
     c.krf = c.kr + c.fresnelRef;
     c.krPos = max3c(c.kr) > 0.0f;
+}
+template <bool SPECTEX = true>
+__device__ __forceinline__ PhongCtx build_phong_ctx(const DevScene& sc, const DevMaterial& m, const SampCtx& s) {
+    PhongCtx c;
+    c.N = normalized3(s.N);
+    if (!s.front) c.N = -c.N;
+    c.V = safe_normalize3(s.V);
+    c.R = safe_normalize3(reflect3(-c.V, c.N));
+    c.kd = eval_tc(sc, m.kd, m.kd_tex, s.uvw);
+    c.ks = eval_tc(sc, m.ks, SPECTEX ? m.ks_tex : -1, s.uvw);
+    c.kr = eval_tc(sc, m.kr, SPECTEX ? m.kr_tex : -1, s.uvw);
+    c.kt = eval_tc(sc, m.kt, SPECTEX ? m.kt_tex : -1, s.uvw);
+    c.alpha = fmaxf(0.001f, eval_tf(sc, m.gloss, SPECTEX ? m.gloss_tex : -1, s.uvw));
+    c.ior = m.ior;
+    finish_phong_ctx(c, s.front);
     return c;
+}
+// true when the raw inputs above are the material's constants (no texture on any of them): what nee_kernel can read itself
+template <bool SPECTEX = true>
+__device__ __forceinline__ bool phong_inputs_constant(const DevMaterial& m) {
+    return m.kd_tex < 0 && (!SPECTEX || (m.ks_tex < 0 && m.kr_tex < 0 && m.kt_tex < 0 && m.gloss_tex < 0));
 }
 
 // Shading.cpp:280-531

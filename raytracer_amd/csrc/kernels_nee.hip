@@ -48,9 +48,10 @@ __global__ __launch_bounds__(NEE_BLOCK) __attribute__((amdgpu_waves_per_eu(NEE_W
         const f3 ldir = mk3(dd.x, dd.y, dd.z);
         l = __float_as_uint(ee.y);
         const float4* rec = pool.neeCtx + __float_as_uint(ee.x);
-        const float4 w0 = NEE_W(rec, 0), w1 = NEE_W(rec, 1), w3 = NEE_W(rec, 3);
+        const float4 w0 = NEE_W(rec, 0), w3 = NEE_W(rec, 3);
         vslot = __float_as_uint(w0.w);
-        const uint32_t vflags = __float_as_uint(w1.z);
+        const uint32_t vflags = __float_as_uint(ee.z);
+        const float alpha = ee.w;
         const f3 vP = mk3(w0.x, w0.y, w0.z), GN = mk3(w3.x, w3.y, w3.z);
         const DevLight& light = sc.lights[l];
         DirInfo li;
@@ -60,11 +61,13 @@ __global__ __launch_bounds__(NEE_BLOCK) __attribute__((amdgpu_waves_per_eu(NEE_W
         sx.front = (vflags & NEEF_FRONT) != 0u;
         DirInfo bs;
         if (MICRO && (vflags & NEEF_MICRO) != 0u) {
-            const MicroCtx mctx = nee_ctx_load_micro(rec, stride, w1.w);
+            const MicroCtx mctx = nee_ctx_load_micro(rec, stride, alpha);
             evaluate_microfacet(mctx, sx, safe_normalize3(ldir), bs);
         } else {
             const bool phong = PHONG && (vflags & NEEF_PHONG) != 0u;
-            const PhongCtx ctx = nee_ctx_load(rec, stride, w1.w, vflags, phong);
+            PhongCtx ctx;
+            if (vflags & NEEF_COMPACT) ctx = nee_ctx_rebuild(sc.mtls[vflags >> 16], NEE_W(rec, 2), NEE_W(rec, 4), sx.front, phong);
+            else ctx = nee_ctx_load(rec, stride, alpha, vflags, phong);
             evaluate_phong_blinn(ctx, phong, sx, safe_normalize3(ldir), bs);
         }
         if (bs.prob > 0.0f && max3c(bs.mult) > 0.0f) {   // RayCaster.cpp:476-501

@@ -8,13 +8,23 @@
 // instead of 128). Written only for vertices that have a pair in the NEE queue.
 //
 //   w0  P.xyz            | path slot
-//   w1  -, -             | flags | alpha
+//   w1  -                                 (flags and alpha travel in the pair's queue entry since round 3: neeQ[2e+1].zw)
 //   w2  N.xyz            | ior            (N: shading normal, flipped to the side of the ray as the context holds it)
 //   w3  GN.xyz           | kd.x
 //   w4  V.xyz            | kd.y
 //   w5  specColor.xyz    | kd.z           microfacet: F0
 //   w6  kr + fresnelRef  | -              microfacet: diffuse.xyz | pd
 //   w7  transColor.xyz   | -              microfacet: trans.xyz   | ps           (kd.xyz = pt, total, -)
+//
+// Compact form (NEEF_COMPACT, round 3): a Blinn / Phong vertex whose material puts no texture on the context's inputs leaves
+// 64 bytes - w0, w2, w3, w4, with the material's index in the upper half of the flags word -
+// and nee_kernel forms kd / specColor / krf / transColor / alpha / ior itself, from the material record, with the arithmetic
+// BuildPhongContext uses (bsdf.h finish_phong_ctx): the same operations on the same operands. nee_kernel moves bytes - 128 of
+// them per pair for this record before - and half a record less took 20 ms off a C3 frame.
+//   w0  P.xyz            | path slot
+//   w2  N.xyz            | -
+//   w3  GN.xyz           | -
+//   w4  V.xyz            | -
 #pragma once
 #include "bsdf.h"
 
@@ -25,14 +35,22 @@
 #define NEEF_CAUSTIC 8u           // a caustics map scales with this vertex's visibility: every light sample needs its shadow ray (RayCaster.cpp:518)
 #define NEEF_KRPOS 16u            // max(kr) > 0 (Shading.cpp:640)
 #define NEEF_PTPOS 32u            // luma(transColor) > 0: light from behind the surface can contribute
+#define NEEF_COMPACT 64u          // compact record: the lobe terms are rebuilt from material (flags >> 16)
 
 #define NEE_W(rec, k) (rec)[(size_t)(k) * stride]
-__device__ __forceinline__ void nee_ctx_store(float4* rec, size_t stride, uint32_t slot, uint32_t flags, f3 P, f3 GN,
-                                              const PhongCtx& c) {
+// the flags word of a vertex's pairs (neeQ[2e+1].z; .w = the context's alpha)
+__device__ __forceinline__ uint32_t nee_flags_phong(uint32_t flags, const PhongCtx& c) {
     if (c.krPos) flags |= NEEF_KRPOS;
     if (luma1(c.transColor) > 0.0f) flags |= NEEF_PTPOS;
+    return flags;
+}
+__device__ __forceinline__ uint32_t nee_flags_micro(uint32_t flags, const MicroCtx& c) {
+    flags |= NEEF_MICRO;
+    if (c.pt > 0.0f) flags |= NEEF_PTPOS;
+    return flags;
+}
+__device__ __forceinline__ void nee_ctx_store(float4* rec, size_t stride, uint32_t slot, f3 P, f3 GN, const PhongCtx& c) {
     NEE_W(rec, 0) = make_float4(P.x, P.y, P.z, __uint_as_float(slot));
-    NEE_W(rec, 1) = make_float4(0.0f, 0.0f, __uint_as_float(flags), c.alpha);
     NEE_W(rec, 2) = make_float4(c.N.x, c.N.y, c.N.z, c.ior);
     NEE_W(rec, 3) = make_float4(GN.x, GN.y, GN.z, c.kd.x);
     NEE_W(rec, 4) = make_float4(c.V.x, c.V.y, c.V.z, c.kd.y);
@@ -40,12 +58,29 @@ __device__ __forceinline__ void nee_ctx_store(float4* rec, size_t stride, uint32
     NEE_W(rec, 6) = make_float4(c.krf.x, c.krf.y, c.krf.z, 0.0f);
     NEE_W(rec, 7) = make_float4(c.transColor.x, c.transColor.y, c.transColor.z, 0.0f);
 }
-__device__ __forceinline__ void nee_ctx_store_micro(float4* rec, size_t stride, uint32_t slot, uint32_t flags, f3 P, f3 GN,
-                                                    const MicroCtx& c) {
-    flags |= NEEF_MICRO;
-    if (c.pt > 0.0f) flags |= NEEF_PTPOS;
+__device__ __forceinline__ void nee_ctx_store_compact(float4* rec, size_t stride, uint32_t slot, f3 P, f3 GN, const PhongCtx& c) {
     NEE_W(rec, 0) = make_float4(P.x, P.y, P.z, __uint_as_float(slot));
-    NEE_W(rec, 1) = make_float4(0.0f, 0.0f, __uint_as_float(flags), c.alpha);
+    NEE_W(rec, 2) = make_float4(c.N.x, c.N.y, c.N.z, 0.0f);
+    NEE_W(rec, 3) = make_float4(GN.x, GN.y, GN.z, 0.0f);
+    NEE_W(rec, 4) = make_float4(c.V.x, c.V.y, c.V.z, 0.0f);
+}
+// ... and its evaluation side: the context BuildPhongContext would build at this vertex (w2, w4: the record's words)
+__device__ __forceinline__ PhongCtx nee_ctx_rebuild(const DevMaterial& m, float4 w2, float4 w4, bool front, bool phong) {
+    PhongCtx c;
+    c.N = mk3(w2.x, w2.y, w2.z);
+    c.V = mk3(w4.x, w4.y, w4.z);
+    c.R = phong ? safe_normalize3(reflect3(-c.V, c.N)) : mk3(0.0f);
+    c.kd = ld3(m.kd);          // TexturedColor::Eval without a map: the value
+    c.ks = ld3(m.ks);
+    c.kr = ld3(m.kr);
+    c.kt = ld3(m.kt);
+    c.alpha = fmaxf(0.001f, m.gloss);
+    c.ior = m.ior;
+    finish_phong_ctx(c, front);
+    return c;
+}
+__device__ __forceinline__ void nee_ctx_store_micro(float4* rec, size_t stride, uint32_t slot, f3 P, f3 GN, const MicroCtx& c) {
+    NEE_W(rec, 0) = make_float4(P.x, P.y, P.z, __uint_as_float(slot));
     NEE_W(rec, 2) = make_float4(c.N.x, c.N.y, c.N.z, c.ior);
     NEE_W(rec, 3) = make_float4(GN.x, GN.y, GN.z, c.pt);
     NEE_W(rec, 4) = make_float4(c.V.x, c.V.y, c.V.z, c.total);
@@ -53,7 +88,7 @@ __device__ __forceinline__ void nee_ctx_store_micro(float4* rec, size_t stride, 
     NEE_W(rec, 6) = make_float4(c.diffuse.x, c.diffuse.y, c.diffuse.z, c.pd);
     NEE_W(rec, 7) = make_float4(c.trans.x, c.trans.y, c.trans.z, c.ps);
 }
-// the evaluation side: words 2..7 of a record (w1 is read by the caller: flags, alpha)
+// the evaluation side: words 2..7 of a record (flags, alpha: the pair's queue entry)
 __device__ __forceinline__ PhongCtx nee_ctx_load(const float4* rec, size_t stride, float alpha, uint32_t flags, bool phong) {
     const float4 w2 = NEE_W(rec, 2), w3 = NEE_W(rec, 3), w4 = NEE_W(rec, 4), w5 = NEE_W(rec, 5), w6 = NEE_W(rec, 6), w7 = NEE_W(rec, 7);
     PhongCtx c;

@@ -208,9 +208,10 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
             if ((flags & PF_INSIDE_MEDIUM) && hitDist > 0.0f) beta = apply_absorption(beta, mediumAbs, hitDist);
 
             const DevMaterial* mtl = nullptr;
+            int mtlIndex = -1;
             if (sh.obj >= 0) {
-                const int mi = sc.objs[sh.obj].material;
-                if (mi >= 0) mtl = &sc.mtls[mi];
+                mtlIndex = sc.objs[sh.obj].material;
+                if (mtlIndex >= 0) mtl = &sc.mtls[mtlIndex];
             }
 #ifndef RTX_ABLATE_BUMP
             if (mtl) apply_bump(sc, *mtl, sh);
@@ -277,6 +278,12 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
                 // record is written only if a pair is left, and pendBeta.w names the lights whose nee records exist.
                 const f3 cN = micro ? mctx.N : ctx.N;
                 const bool behindToo = wantCaustic || (micro ? mctx.pt > 0.0f : luma1(ctx.transColor) > 0.0f);
+                // what every pair of this vertex carries in its queue entry: the flags word and the context's alpha (nee_ctx.h)
+                const bool compactRec = !micro && mtlIndex < 65536 && phong_inputs_constant<PHONG>(*mtl);
+                uint32_t nf = (sx.front ? NEEF_FRONT : 0u) | (phong ? NEEF_PHONG : 0u) | (wantCaustic ? NEEF_CAUSTIC : 0u);
+                nf = micro ? nee_flags_micro(nf, mctx) : nee_flags_phong(nf, ctx);
+                if (compactRec) nf |= NEEF_COMPACT | ((uint32_t)mtlIndex << 16);
+                const float recAlpha = micro ? mctx.alpha : ctx.alpha;
                 uint32_t lightMask = 0u;
 #ifdef RTX_ABLATE_NEE
                 for (int l0 = 0; l0 < 0; l0 += 4) {
@@ -319,17 +326,17 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
                             if ((lightMask >> (l0 + k)) & 1u) {
                                 const size_t e = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[k], 0u));
                                 pool.neeQ[2 * e] = make_float4(ld[k].x, ld[k].y, ld[k].z, dd[k]);
-                                pool.neeQ[2 * e + 1] = make_float4(__uint_as_float(neeIndex), __uint_as_float((uint32_t)(l0 + k)), 0.0f, 0.0f);
+                                pool.neeQ[2 * e + 1] = make_float4(__uint_as_float(neeIndex), __uint_as_float((uint32_t)(l0 + k)), __uint_as_float(nf), recAlpha);
                             }
                             at += (uint32_t)__popcll(bal[k]);
                         }
                     }
                 }
                 if (lightMask) {
-                    const uint32_t nf = (sx.front ? NEEF_FRONT : 0u) | (phong ? NEEF_PHONG : 0u) | (wantCaustic ? NEEF_CAUSTIC : 0u);
                     float4* rec = pool.neeCtx + neeIndex;
-                    if (micro) nee_ctx_store_micro(rec, pool.neeStride, ws, nf, sh.p, sx.GN, mctx);
-                    else nee_ctx_store(rec, pool.neeStride, ws, nf, sh.p, sx.GN, ctx);
+                    if (micro) nee_ctx_store_micro(rec, pool.neeStride, ws, sh.p, sx.GN, mctx);
+                    else if (compactRec) nee_ctx_store_compact(rec, pool.neeStride, ws, sh.p, sx.GN, ctx);
+                    else nee_ctx_store(rec, pool.neeStride, ws, sh.p, sx.GN, ctx);
                     pending = true;
                     pendMask = lightMask;
                 }
