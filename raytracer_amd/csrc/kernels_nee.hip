@@ -46,12 +46,12 @@ __global__ __launch_bounds__(NEE_BLOCK) __attribute__((amdgpu_waves_per_eu(NEE_W
         const size_t e = segq_item_index(qtab, i);
         const float4 dd = pool.neeQ[2 * e], ee = pool.neeQ[2 * e + 1];
         const f3 ldir = mk3(dd.x, dd.y, dd.z);
-        l = __float_as_uint(ee.y);
+        const uint32_t vflags = __float_as_uint(ee.z);   // NEEF_ flags | light << 8 | material << 16 (nee_ctx.h)
+        const float alpha = ee.w;
+        l = (vflags >> 8) & 0xFFu;
+        vslot = __float_as_uint(ee.y);
         const float4* rec = pool.neeCtx + __float_as_uint(ee.x);
         const float4 w0 = NEE_W(rec, 0), w3 = NEE_W(rec, 3);
-        vslot = __float_as_uint(w0.w);
-        const uint32_t vflags = __float_as_uint(ee.z);
-        const float alpha = ee.w;
         const f3 vP = mk3(w0.x, w0.y, w0.z), GN = mk3(w3.x, w3.y, w3.z);
         const DevLight& light = sc.lights[l];
         DirInfo li;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(NEE_BLOCK) __attribute__((amdgpu_waves_per_eu(NEE_W
         } else {
             const bool phong = PHONG && (vflags & NEEF_PHONG) != 0u;
             PhongCtx ctx;
-            if (vflags & NEEF_COMPACT) ctx = nee_ctx_rebuild(sc.mtls[vflags >> 16], NEE_W(rec, 2), NEE_W(rec, 4), sx.front, phong);
+            if (vflags & NEEF_COMPACT) ctx = nee_ctx_rebuild(sc.mtls[vflags >> 16], w0, NEE_W(rec, 2), w3, sx.front, phong);
             else ctx = nee_ctx_load(rec, stride, alpha, vflags, phong);
             evaluate_phong_blinn(ctx, phong, sx, safe_normalize3(ldir), bs);
         }

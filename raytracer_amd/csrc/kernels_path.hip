@@ -101,7 +101,7 @@ __global__ void raygen_kernel(DevCamera cam, PathPool pool, const int* __restric
             }
             pool.rays[2 * (size_t)slot] = make_float4(ro.x, ro.y, ro.z, RTX_BIG);
             pool.rays[2 * (size_t)slot + 1] = make_float4(rd.x, rd.y, rd.z, 0.0f);
-            // L / beta / medium start as {0, BIG}, {1, 1}, {0, PF_LAST_DELTA}: the shading of bounce 0 assumes that (shade_body.h)
+            // L / beta / flags start as {0, BIG}, {1, 1}, PF_LAST_DELTA: the shading of bounce 0 assumes that (shade_body.h)
             if (initGuides) {
                 pool.pendBeta[slot] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);   // nothing to resolve (resolve_add)
                 pool.albedo[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(RTX_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu
         // and leaves the vertex's record at index i of pool.neeCtx
         const uint32_t ws = REPACK ? wbase + i : slot;
         const uint32_t os = REPACK ? path_origin(pool, slot) : 0u;
-        alive = shade_body<MICRO, false, PHOT, PHONG, true>(sc, cam, pool, pm, slot, ray, HitT{hv.x, hv.y, hv.z, hitSlot}, bounce, maxBounces,
+        alive = shade_body<MICRO, false, PHOT, PHONG, true>(sc, cam, pool, pm, slot, ray, __float_as_uint(rb.w), HitT{hv.x, hv.y, hv.z, hitSlot}, bounce, maxBounces,
                                                             seed, sBase, S, pixels, qShadow, i, &qNee, scArg.lights, ws, &culled);
         if (REPACK) {
             // (a culled vertex stays where it is: the general tail kernel finishes its path there)

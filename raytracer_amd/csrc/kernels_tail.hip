@@ -64,9 +64,11 @@ __global__ __launch_bounds__(TRAV_BLOCK) void tail_kernel(DevScene scArg, DevCam
         if (!(needExtend || haveVertex)) continue;
         // ---- one step of this quad's path: trace (next ray + shadows of the last vertex), resolve, shade ----
         RayT ray{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f};
+        uint32_t rayFlags = 0u;   // the path's PF_ flags travel with its ray (shade_body.h)
         if (needExtend) {
             const float4 ra = pool.rays[2 * (size_t)slot], rb = pool.rays[2 * (size_t)slot + 1];
             ray = RayT{ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, ra.w};
+            rayFlags = __float_as_uint(rb.w);
         }
         HitT hit{RTX_BIG, 0.0f, 0.0f, -1};
         const int nJobs = 1 + (haveVertex ? nL : 0);
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void tail_kernel(DevScene scArg, DevCam
         haveVertex = false;
         if (needExtend) {
             // MICRO here = "general": microfacet or Phong materials, textured specular terms, or a caustics map (launch_tail)
-            needExtend = shade_body<MICRO, true, MICRO, MICRO>(sc, cam, pool, pm, slot, ray, hit, bounce, maxBounces, seed, sBase, S, pixels, SegQ{nullptr});
+            needExtend = shade_body<MICRO, true, MICRO, MICRO>(sc, cam, pool, pm, slot, ray, rayFlags, hit, bounce, maxBounces, seed, sBase, S, pixels, SegQ{nullptr});
             // the NEE entries are this vertex's only when the body left something pending (a path that ended on a miss
             // or a light never reached its NEE loop: the entries then hold an older vertex's values)
             haveVertex = pool.pendBeta[slot].w >= 0.0f;

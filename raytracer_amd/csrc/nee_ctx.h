@@ -7,8 +7,8 @@
 // store (as one record per lane, every store touched 64 different lines with 16 bytes each: 512 write requests per wave
 // instead of 128). Written only for vertices that have a pair in the NEE queue.
 //
-//   w0  P.xyz            | path slot
-//   w1  -                                 (flags and alpha travel in the pair's queue entry since round 3: neeQ[2e+1].zw)
+//   w0  P.xyz            | -              (the path slot, the flags and alpha travel in the pair's queue entry since round 3:
+//   w1  -                                  neeQ[2e+1] = {vertex index, path slot, flags | light << 8 | material << 16, alpha})
 //   w2  N.xyz            | ior            (N: shading normal, flipped to the side of the ray as the context holds it)
 //   w3  GN.xyz           | kd.x
 //   w4  V.xyz            | kd.y
@@ -17,14 +17,13 @@
 //   w7  transColor.xyz   | -              microfacet: trans.xyz   | ps           (kd.xyz = pt, total, -)
 //
 // Compact form (NEEF_COMPACT, round 3): a Blinn / Phong vertex whose material puts no texture on the context's inputs leaves
-// 64 bytes - w0, w2, w3, w4, with the material's index in the upper half of the flags word -
+// 48 bytes - w0, w2, w3, the view direction in their spare words, and the material's index in the upper half of the flags word -
 // and nee_kernel forms kd / specColor / krf / transColor / alpha / ior itself, from the material record, with the arithmetic
 // BuildPhongContext uses (bsdf.h finish_phong_ctx): the same operations on the same operands. nee_kernel moves bytes - 128 of
 // them per pair for this record before - and half a record less took 20 ms off a C3 frame.
-//   w0  P.xyz            | path slot
-//   w2  N.xyz            | -
-//   w3  GN.xyz           | -
-//   w4  V.xyz            | -
+//   w0  P.xyz            | V.x
+//   w2  N.xyz            | V.y
+//   w3  GN.xyz           | V.z
 #pragma once
 #include "bsdf.h"
 
@@ -49,8 +48,8 @@ __device__ __forceinline__ uint32_t nee_flags_micro(uint32_t flags, const MicroC
     if (c.pt > 0.0f) flags |= NEEF_PTPOS;
     return flags;
 }
-__device__ __forceinline__ void nee_ctx_store(float4* rec, size_t stride, uint32_t slot, f3 P, f3 GN, const PhongCtx& c) {
-    NEE_W(rec, 0) = make_float4(P.x, P.y, P.z, __uint_as_float(slot));
+__device__ __forceinline__ void nee_ctx_store(float4* rec, size_t stride, f3 P, f3 GN, const PhongCtx& c) {
+    NEE_W(rec, 0) = make_float4(P.x, P.y, P.z, 0.0f);
     NEE_W(rec, 2) = make_float4(c.N.x, c.N.y, c.N.z, c.ior);
     NEE_W(rec, 3) = make_float4(GN.x, GN.y, GN.z, c.kd.x);
     NEE_W(rec, 4) = make_float4(c.V.x, c.V.y, c.V.z, c.kd.y);
@@ -58,17 +57,16 @@ __device__ __forceinline__ void nee_ctx_store(float4* rec, size_t stride, uint32
     NEE_W(rec, 6) = make_float4(c.krf.x, c.krf.y, c.krf.z, 0.0f);
     NEE_W(rec, 7) = make_float4(c.transColor.x, c.transColor.y, c.transColor.z, 0.0f);
 }
-__device__ __forceinline__ void nee_ctx_store_compact(float4* rec, size_t stride, uint32_t slot, f3 P, f3 GN, const PhongCtx& c) {
-    NEE_W(rec, 0) = make_float4(P.x, P.y, P.z, __uint_as_float(slot));
-    NEE_W(rec, 2) = make_float4(c.N.x, c.N.y, c.N.z, 0.0f);
-    NEE_W(rec, 3) = make_float4(GN.x, GN.y, GN.z, 0.0f);
-    NEE_W(rec, 4) = make_float4(c.V.x, c.V.y, c.V.z, 0.0f);
+__device__ __forceinline__ void nee_ctx_store_compact(float4* rec, size_t stride, f3 P, f3 GN, const PhongCtx& c) {
+    NEE_W(rec, 0) = make_float4(P.x, P.y, P.z, c.V.x);
+    NEE_W(rec, 2) = make_float4(c.N.x, c.N.y, c.N.z, c.V.y);
+    NEE_W(rec, 3) = make_float4(GN.x, GN.y, GN.z, c.V.z);
 }
-// ... and its evaluation side: the context BuildPhongContext would build at this vertex (w2, w4: the record's words)
-__device__ __forceinline__ PhongCtx nee_ctx_rebuild(const DevMaterial& m, float4 w2, float4 w4, bool front, bool phong) {
+// ... and its evaluation side: the context BuildPhongContext would build at this vertex (w0, w2, w3: the record's words)
+__device__ __forceinline__ PhongCtx nee_ctx_rebuild(const DevMaterial& m, float4 w0, float4 w2, float4 w3, bool front, bool phong) {
     PhongCtx c;
     c.N = mk3(w2.x, w2.y, w2.z);
-    c.V = mk3(w4.x, w4.y, w4.z);
+    c.V = mk3(w0.w, w2.w, w3.w);
     c.R = phong ? safe_normalize3(reflect3(-c.V, c.N)) : mk3(0.0f);
     c.kd = ld3(m.kd);          // TexturedColor::Eval without a map: the value
     c.ks = ld3(m.ks);
@@ -79,8 +77,8 @@ __device__ __forceinline__ PhongCtx nee_ctx_rebuild(const DevMaterial& m, float4
     finish_phong_ctx(c, front);
     return c;
 }
-__device__ __forceinline__ void nee_ctx_store_micro(float4* rec, size_t stride, uint32_t slot, f3 P, f3 GN, const MicroCtx& c) {
-    NEE_W(rec, 0) = make_float4(P.x, P.y, P.z, __uint_as_float(slot));
+__device__ __forceinline__ void nee_ctx_store_micro(float4* rec, size_t stride, f3 P, f3 GN, const MicroCtx& c) {
+    NEE_W(rec, 0) = make_float4(P.x, P.y, P.z, 0.0f);
     NEE_W(rec, 2) = make_float4(c.N.x, c.N.y, c.N.z, c.ior);
     NEE_W(rec, 3) = make_float4(GN.x, GN.y, GN.z, c.pt);
     NEE_W(rec, 4) = make_float4(c.V.x, c.V.y, c.V.z, c.total);

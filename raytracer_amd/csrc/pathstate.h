@@ -43,7 +43,7 @@ struct PathPool {
     float4* hits;           // {t, u, v, bits(slot of triangle / light code)}
     float4* L;              // radiance rgb, w = primaryDist
     float4* beta;           // throughput rgb, w = lastPdf
-    float4* medium;         // absorption rgb, w = bits(flags)
+    float4* medium;         // absorption rgb of the medium a path is inside of (PF_INSIDE_MEDIUM; the flags travel in rays[2*slot+1].w)
     float4* prevP;          // previous hit point (SamplerInfo of the previous bounce), xyz
     float4* pendBeta;       // throughput at the NEE of the current bounce
     float4* nee;            // [light][slot]: contribution rgb, w = transmittance (-1: no shadow ray)
@@ -56,7 +56,7 @@ struct PathPool {
     uint32_t* queueA;
     uint32_t* queueB;
     float4* shadowQ;        // 2 per entry: {offset origin xyz, maxDist}, {unit dir xyz, bits(slot*8+light)}
-    float4* neeQ;           // 2 per entry: {direction to the sampled point on the light, its distance}, {bits(vertex index of the bounce), bits(light)}
+    float4* neeQ;           // 2 per entry: {direction to the sampled point on the light, its distance}, {bits(vertex index of the bounce), bits(path slot), bits(flags | light << 8 | material << 16), alpha} (nee_ctx.h)
     SegQ qA, qB, qS, qN;    // control words of queueA / queueB / shadowQ / neeQ
     size_t neeStride;       // vertices the record array is laid out for (word k of vertex i at neeCtx[k * neeStride + i])
     float4* neeCtx;         // NEE_CTX_VEC per vertex of the current bounce, indexed by queue position (nee_ctx.h): shade_kernel -> nee_kernel

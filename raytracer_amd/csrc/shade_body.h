@@ -115,9 +115,11 @@ __device__ __forceinline__ void resolve_slot(const PathPool& pool, uint32_t slot
 // moves the paths together (pathstate.h "Compaction"; shade_kernel<..., REPACK>): everything the body reads is at `slot`,
 // everything it leaves for later kernels (path state, next ray, NEE records and their slot word) at ws. The first-hit guides
 // stay with the slot the path was generated in, where film_kernel looks for them.
+// rayFlags: the path's PF_ flags, which travel in the spare word of its ray (pool.rays[2 * slot + 1].w) since round 3: the medium
+// record is then read and written only by paths inside a medium, not by every vertex (32 bytes per vertex less).
 template <bool MICRO, bool TAIL, bool PHOT = true, bool PHONG = true, bool SPLIT = false>
 __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& cam, const PathPool& pool, const DevPhotonMap& pmArg,
-                                           uint32_t slot, const RayT& ray, const HitT& h, int bounce, int maxBounces,
+                                           uint32_t slot, const RayT& ray, uint32_t rayFlags, const HitT& h, int bounce, int maxBounces,
                                            unsigned long long seed, int sBase, int S, const int* __restrict__ pixels,
                                            const SegQ& qShadow, uint32_t neeIndex = 0u, const SegQ* qNee = nullptr,
                                            const DevLight* lightsArg = nullptr, uint32_t ws = 0xFFFFFFFFu, bool* culledOut = nullptr) {
@@ -134,11 +136,13 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
         // a camera ray carries the initial path state (raygen_kernel does not write it out: 48 B per path saved each way)
         float4 L4 = make_float4(0.0f, 0.0f, 0.0f, RTX_BIG);
         float4 b4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-        float4 m4 = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(PF_LAST_DELTA));
+        float4 m4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        uint32_t flags = PF_LAST_DELTA;
         if (bounce > 0) {
             L4 = pool.L[slot];
             b4 = pool.beta[slot];
-            m4 = pool.medium[slot];
+            flags = rayFlags;
+            if (flags & PF_INSIDE_MEDIUM) m4 = pool.medium[slot];
         }
         f3 L = mk3(L4.x, L4.y, L4.z);
 #ifndef RTX_ABLATE_RESOLVE   // (RTX_ABLATE_*: timing-only builds of tools/build_variant.sh that leave a part of the body out; wrong images)
@@ -146,7 +150,6 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
 #endif
         f3 beta = mk3(b4.x, b4.y, b4.z);
         float lastPdf = b4.w;
-        uint32_t flags = __float_as_uint(m4.w);
         f3 mediumAbs = mk3(m4.x, m4.y, m4.z);
         const f3 rdir = mk3(ray.dx, ray.dy, ray.dz), rorg = mk3(ray.ox, ray.oy, ray.oz);
         // pixel / sample of this path -> RNG key
@@ -326,7 +329,7 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
                             if ((lightMask >> (l0 + k)) & 1u) {
                                 const size_t e = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[k], 0u));
                                 pool.neeQ[2 * e] = make_float4(ld[k].x, ld[k].y, ld[k].z, dd[k]);
-                                pool.neeQ[2 * e + 1] = make_float4(__uint_as_float(neeIndex), __uint_as_float((uint32_t)(l0 + k)), __uint_as_float(nf), recAlpha);
+                                pool.neeQ[2 * e + 1] = make_float4(__uint_as_float(neeIndex), __uint_as_float(ws), __uint_as_float(nf | ((uint32_t)(l0 + k) << 8)), recAlpha);
                             }
                             at += (uint32_t)__popcll(bal[k]);
                         }
@@ -334,9 +337,9 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
                 }
                 if (lightMask) {
                     float4* rec = pool.neeCtx + neeIndex;
-                    if (micro) nee_ctx_store_micro(rec, pool.neeStride, ws, sh.p, sx.GN, mctx);
-                    else if (compactRec) nee_ctx_store_compact(rec, pool.neeStride, ws, sh.p, sx.GN, ctx);
-                    else nee_ctx_store(rec, pool.neeStride, ws, sh.p, sx.GN, ctx);
+                    if (micro) nee_ctx_store_micro(rec, pool.neeStride, sh.p, sx.GN, mctx);
+                    else if (compactRec) nee_ctx_store_compact(rec, pool.neeStride, sh.p, sx.GN, ctx);
+                    else nee_ctx_store(rec, pool.neeStride, sh.p, sx.GN, ctx);
                     pending = true;
                     pendMask = lightMask;
                 }
@@ -434,7 +437,7 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
             const f3 no = offset_point(sh.p, sx.GN, nextDir);
             const f3 nd = safe_normalize3(nextDir);
             pool.rays[2 * (size_t)ws] = make_float4(no.x, no.y, no.z, RTX_BIG);
-            pool.rays[2 * (size_t)ws + 1] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+            pool.rays[2 * (size_t)ws + 1] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(flags));
             alive = true;
         } while (false);
 
@@ -443,8 +446,10 @@ __device__ __forceinline__ bool shade_body(const DevScene& sc, const DevCamera& 
             return false;
         }
         pool.L[ws] = make_float4(L.x, L.y, L.z, L4.w);
-        pool.beta[ws] = make_float4(beta.x, beta.y, beta.z, lastPdf);
-        pool.medium[ws] = make_float4(mediumAbs.x, mediumAbs.y, mediumAbs.z, __uint_as_float(flags));
+        if (alive) {   // (a path that has ended leaves its radiance and what is pending; nobody reads the rest)
+            pool.beta[ws] = make_float4(beta.x, beta.y, beta.z, lastPdf);
+            if (flags & PF_INSIDE_MEDIUM) pool.medium[ws] = make_float4(mediumAbs.x, mediumAbs.y, mediumAbs.z, 0.0f);
+        }
         if (!pending) {
             // mark "nothing to resolve" for resolve_add
             pool.pendBeta[ws] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
