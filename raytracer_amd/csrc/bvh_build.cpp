@@ -525,6 +525,19 @@ struct Emitter {
 
 }  // namespace
 
+// The words of each TriRec the shading reads, next to the triangle's attributes (layout.h TriAttr): once the records are final
+static void copy_records_to_attrs(HostScene& out) {
+    for (size_t i = 0; i < out.tris.size() && i < out.attrs.size(); ++i) {
+        const TriRec& r = out.tris[i];
+        TriAttr& a = out.attrs[i];
+        a.e1x = r.e1x; a.e1y = r.e1y; a.e1z = r.e1z;
+        a.kind = r.kind;
+        a.e2x = r.e2x; a.e2y = r.e2y; a.e2z = r.e2z;
+        a.obj = r.obj;
+        a.prim = r.prim;
+    }
+}
+
 bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& err) {
     out = HostScene();
     if (!desc || desc->n_meshes < 0) {
@@ -733,6 +746,7 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
         err = E.err;
         return false;
     }
+    copy_records_to_attrs(out);
     return true;
 #else
     out.root = E.emit(root, 0);
@@ -777,6 +791,7 @@ bool build_host_scene(const rtx_scene_desc* desc, HostScene& out, std::string& e
             }
         if (interior) r.obj |= TRI_INTERIOR;
     }
+    copy_records_to_attrs(out);
     return true;
 #endif
 }

@@ -17,6 +17,8 @@
 // Random numbers: Shade() number `node` of the tree (root 0; children 3*node+1 diffuse, +2 reflection, +3 refraction)
 // draws from the counter generator keyed (pixel, sample) x node x draw slot, identically in oracle/oracle_legacy.cpp.
 #define RTX_TRAV_SLAB_TWO_OPS 1   // traverse.h trav_inner_step: see there
+#define RTX_RESOLVE_TWO_ARRAYS 1 // surface.h resolve_triangle: edges and words from the TriRec, not from its copy in TriAttr (the register
+                                 // allocation of this kernel with the one-line form puts a spill store before a lane re-enable: tools/check_spill_exec.py)
 #include "shade_body.h"
 
 #define LG_MAX_BOUNCES 5        // ShadeInfoAdapter::kMaxSpecularBounces (:245)

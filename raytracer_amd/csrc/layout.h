@@ -7,7 +7,7 @@
 //
 //   Node4   64 B   origin (3 x f32) + 3 power-of-two scales + 4 x (6 x u8 box) + 4 child references
 //   TriRec  48 B   v0, e1 = v1-v0, e2 = v2-v0 (the operands of objects.cpp:146-151) + global triangle id
-//   TriAttr 64 B   vertex normals, texture coordinates, object / material id (objects.cpp:181-236)
+//   TriAttr 128 B  vertex normals, texture coordinates, object / material id (objects.cpp:181-236) + the record's edges and words
 //
 // TriRec and TriAttr are stored in BVH (depth-first leaf) order so that neighbouring hits touch neighbouring
 // memory; a leaf references up to 4 consecutive records (leaf size 4 as in bvh.SetMesh(this, 4)).
@@ -91,12 +91,21 @@ static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
 #define TRI_INTERIOR 0x40000000u
 #define TRI_INTERIOR_TMAX 1000.0f
 
+// One 128-byte line per triangle holds everything the shading of a hit reads (surface.h resolve_triangle): the attributes and
+// a copy of the TriRec words it needs (edges, kind, object word, primitive id). A hit used to fetch its TriRec (48 bytes that
+// straddle a line one time in four) and its attributes (64 bytes) from two arrays - 2.25 lines of 128 bytes - for 100 bytes used.
 struct TriAttr {
     float n0[3], n1[3], n2[3];
     float uv0[2], uv1[2], uv2[2];
     uint32_t obj_mtl;       // obj | (mtlID << 16)
+    float e1x, e1y, e1z;    // = TriRec (copied when the build ends: bvh_build.cpp)
+    uint32_t kind;
+    float e2x, e2y, e2z;
+    uint32_t obj;
+    uint32_t prim;
+    uint32_t pad[7];
 };
-static_assert(sizeof(TriAttr) == 64, "TriAttr must be 64 bytes");
+static_assert(sizeof(TriAttr) == 128, "TriAttr must be 128 bytes");
 
 #define OBJ_HAS_NORMALS 1u
 #define OBJ_HAS_TEXCOORDS 2u

@@ -183,10 +183,20 @@ __device__ __forceinline__ void resolve_analytic(const DevScene& sc, uint32_t ki
 
 // HitInfo of a triangle hit: objects.cpp:172-240
 __device__ __forceinline__ void resolve_triangle(const DevScene& sc, const RayT& r, const HitT& h, SurfHit& s) {
+#ifdef RTX_RESOLVE_TWO_ARRAYS   // (kernels_legacy.hip: the same words from the TriRec itself, as before round 3 - see there)
     const float4* tris4 = reinterpret_cast<const float4*>(sc.tris);
     const float4 a = tris4[(size_t)h.slot * 3 + 0];
     const float4 b = tris4[(size_t)h.slot * 3 + 1];
     const float4 c = tris4[(size_t)h.slot * 3 + 2];
+    const uint32_t prim = __float_as_uint(a.w);
+#else
+    // one 128-byte line: the attributes and the copy of the record's words (layout.h TriAttr), all requested before the first
+    // of them is looked at
+    const float4* at4 = reinterpret_cast<const float4*>(sc.attrs + h.slot);
+    const float4 q0 = at4[0], q1 = at4[1], q2 = at4[2], q3 = at4[3];
+    const float4 b = at4[4], c = at4[5];
+    const uint32_t prim = sc.attrs[h.slot].prim;
+#endif
     const uint32_t kind = __float_as_uint(b.w);
     s.triWord = 0u;
     if (kind != 0u && kind != RTX_KIND_XFTRI) {
@@ -202,8 +212,10 @@ __device__ __forceinline__ void resolve_triangle(const DevScene& sc, const RayT&
         ray_to_object(sc, __float_as_uint(c.w) & TRI_OBJ_MASK, r, p, d);
         rr = RayT{p[0], p[1], p[2], d[0], d[1], d[2], r.tmax};
     }
+#ifdef RTX_RESOLVE_TWO_ARRAYS
     const float4* at4 = reinterpret_cast<const float4*>(sc.attrs + h.slot);
     const float4 q0 = at4[0], q1 = at4[1], q2 = at4[2], q3 = at4[3];
+#endif
     const uint32_t obj_mtl = __float_as_uint(q3.w);
     const int obj = (int)(obj_mtl & 0xFFFFu);
     const ObjRec o = sc.objs[obj];
@@ -231,7 +243,7 @@ __device__ __forceinline__ void resolve_triangle(const DevScene& sc, const RayT&
     s.N = N;
     s.obj = obj;
     s.mtlID = (int)(obj_mtl >> 16);
-    s.face = (int)__float_as_uint(a.w) - o.face_base;
+    s.face = (int)prim - o.face_base;
     s.light = -1;
     s.dpdu = mk3(0.0f);
     s.dpdv = mk3(0.0f);
