@@ -26,12 +26,22 @@ __device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
 }
 
 // ---- sampler (RayCaster.cpp:65-81, 784-796, 729-762) --------------------------------------------------------
+// The reference's loop runs while digits are left (`for (i = index; i > 0; i /= BASE)`) and divides f by the base once per digit.
+// Here it runs over every digit a positive int can have: the digits beyond the first add f * 0 = +0 to r, which leaves r as it
+// is, and with the trip count fixed the loop unrolls and the chain f = 1/B, f/B, f/B/B, ... is folded at compile time (one IEEE
+// division per step there as here), so no division is left in the kernel. (raygen_kernel is 1-2 ms of a C3 frame either way.)
 template <int BASE>
 __device__ __forceinline__ float halton(int index) {
+    constexpr int DIGITS = BASE == 2 ? 31 : BASE == 3 ? 20 : BASE == 5 ? 14 : BASE == 7 ? 12 : 31;
+    static_assert(BASE == 2 || BASE == 3 || BASE == 5 || BASE == 7, "digit counts above are for these bases");
     float r = 0.0f;
+    if (index <= 0) return r;
     float f = 1.0f / (float)BASE;
-    for (int i = index; i > 0; i /= BASE) {
-        r += f * (float)(i % BASE);
+    uint32_t i = (uint32_t)index;
+#pragma unroll
+    for (int k = 0; k < DIGITS; ++k) {
+        r += f * (float)(i % (uint32_t)BASE);
+        i /= (uint32_t)BASE;
         f /= (float)BASE;
     }
     return r;

@@ -524,6 +524,9 @@ static int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_render_par
                     tm.nextItems = cnt[1];
                     tm.begin(1, sst);
                     launch_shadow(s->dev, side ? sideCfg : s->cfg, pool, pool.qS, cnt[1], (bounce <= 8 ? 1 : 0) | shadowFlags);   // useTransmittance (RayCaster.cpp:454)
+                    // (the chains the lean kernel set aside - a few dozen per frame - through the general kernel: two blocks that follow
+                    // one ray at a time, 90 us when a bounce has any; moving them to the side stream, beside the next bounce's extend
+                    // launch, was measured and changes nothing: 668 against 667 ms per C3 frame)
                     if (culls) launch_shadow_culled(devGeneral, side ? sideCfg : s->cfg, pool, ph->qCull, (bounce <= 8 ? 1 : 0) | shadowFlags);
                     tm.end(sst);
                     out.shadow_launches++;
