@@ -91,7 +91,8 @@ __global__ __launch_bounds__(NEE_BLOCK) __attribute__((amdgpu_waves_per_eu(NEE_W
         sd = safe_normalize3(ldir);
     }
     // regions of the shadow queue by the blocks that hold pairs, not by the grid (an upper bound): segq_append_g
-    const uint32_t qs = segq_append_g(qShadow, need, 1u, (qtab[QSEG] + NEE_BLOCK - 1u) / NEE_BLOCK);
+    __shared__ uint32_t qtmp[SEGQ_BLOCK_WORDS];
+    const uint32_t qs = segq_append_block(qShadow, need, 1u, (qtab[QSEG] + NEE_BLOCK - 1u) / NEE_BLOCK, qtmp);
     if (need) {
         pool.shadowQ[2 * (size_t)qs] = make_float4(so.x, so.y, so.z, shadowMax);
         pool.shadowQ[2 * (size_t)qs + 1] = make_float4(sd.x, sd.y, sd.z, __uint_as_float(vslot * 8u + l));

@@ -120,7 +120,8 @@ __global__ void raygen_kernel(DevCamera cam, PathPool pool, const int* __restric
             pool.samplePos[slot] = make_float2(samplePosX, samplePosY);
         }
     }
-    const uint32_t q = segq_append(qOut, valid, 1u);
+    __shared__ uint32_t qtmp[SEGQ_BLOCK_WORDS];
+    const uint32_t q = segq_append_block(qOut, valid, 1u, gridDim.x, qtmp);
     if (valid) queueOut[q] = slot;
 }
 
@@ -198,7 +199,8 @@ __global__ __launch_bounds__(RTX_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu
         slot = ws;
     }
     // ---- surviving paths -> next queue ----
-    const uint32_t q = segq_append(qOut, alive, 1u);
+    __shared__ uint32_t qtmp[SEGQ_BLOCK_WORDS];
+    const uint32_t q = segq_append_block(qOut, alive, 1u, gridDim.x, qtmp);
     if (alive) queueOut[q] = slot;
 }
 
