@@ -32,10 +32,17 @@
 template <bool MICRO, bool PHONG>
 __global__ __launch_bounds__(NEE_BLOCK) __attribute__((amdgpu_waves_per_eu(NEE_WAVES_PER_EU))) void nee_kernel(DevScene sc, PathPool pool, SegQ qIn, uint32_t nBound, SegQ qShadow) {
     __shared__ uint32_t qtab[SEGQ_TABLE_WORDS];
-    if (blockIdx.x * NEE_BLOCK >= qIn.ctl[SEGQ_PREFIX + QSEG]) return;   // (block-uniform)
+    // The pair queue's segments are interleaved (SegQ::run: shade_kernel's blocks in flight append through 64 counters), so its
+    // flat order goes 64 times over the vertices of the bounce. The blocks therefore take the flat chunks in transposed order -
+    // block j the chunk (j % 64) * rows + j / 64, about the same place of segment j % 64 as its neighbours take of theirs -
+    // and the shadow queue, which keeps the order of these blocks, holds the segments in the order of the vertices again.
+    const uint32_t total = qIn.ctl[SEGQ_PREFIX + QSEG];
+    const uint32_t rows = segq_nee_rows(total, NEE_BLOCK);
+    const uint32_t chunkIdx = (blockIdx.x % QSEG) * rows + blockIdx.x / QSEG;   // (in flat order: shadow 153 -> 159 ms per C3 frame)
+    if (blockIdx.x >= QSEG * rows || chunkIdx * NEE_BLOCK >= total) return;   // (block-uniform)
     segq_load_table(qIn, qtab);
     __syncthreads();
-    const uint32_t i = blockIdx.x * NEE_BLOCK + threadIdx.x;
+    const uint32_t i = chunkIdx * NEE_BLOCK + threadIdx.x;
     const bool valid = i < nBound && i < qtab[QSEG];
     const size_t stride = pool.neeStride;
     bool need = false;
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(NEE_BLOCK) __attribute__((amdgpu_waves_per_eu(NEE_W
     }
     // regions of the shadow queue by the blocks that hold pairs, not by the grid (an upper bound): segq_append_g
     __shared__ uint32_t qtmp[SEGQ_BLOCK_WORDS];
-    const uint32_t qs = segq_append_block(qShadow, need, 1u, (qtab[QSEG] + NEE_BLOCK - 1u) / NEE_BLOCK, qtmp);
+    const uint32_t qs = segq_append_block(qShadow, need, 1u, QSEG * rows, qtmp);
     if (need) {
         pool.shadowQ[2 * (size_t)qs] = make_float4(so.x, so.y, so.z, shadowMax);
         pool.shadowQ[2 * (size_t)qs + 1] = make_float4(sd.x, sd.y, sd.z, __uint_as_float(vslot * 8u + l));
@@ -106,7 +113,7 @@ uint32_t launch_nee(const DevScene& sc, const PathPool& pool, uint32_t n, const 
     if (!n || sc.n_lights <= 0) return 0;
     const unsigned long long bound = pairs ? (unsigned long long)pairs : (unsigned long long)n * (unsigned long long)sc.n_lights;
     const uint32_t nBound = (uint32_t)(bound > 0xFFFFFF00ull ? 0xFFFFFF00ull : bound);   // (the pool holds fewer than 2^32 shadow segments: rtx_render.cpp)
-    const uint32_t grid = (nBound + NEE_BLOCK - 1) / NEE_BLOCK;
+    const uint32_t grid = QSEG * segq_nee_rows(nBound, NEE_BLOCK);   // (covers the kernel's own QSEG x rows, which comes from the true count)
 #define RTX_LAUNCH_NEE(M, G) hipLaunchKernelGGL((nee_kernel<M, G>), dim3(grid), dim3(NEE_BLOCK), 0, stream, sc, pool, pool.qN, nBound, qShadow)
     switch (materialKinds & 3) {
         case 0: RTX_LAUNCH_NEE(false, false); break;

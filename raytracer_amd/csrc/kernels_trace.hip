@@ -13,7 +13,7 @@ __global__ void segq_scan_kernel(SegQ qa, uint32_t Ga, uint32_t Ba, uint32_t mul
     const SegQ q = blockIdx.x == 0 ? qa : qb;
     uint32_t G = blockIdx.x == 0 ? Ga : Gb;
     const uint32_t B = blockIdx.x == 0 ? Ba : Bb, mult = blockIdx.x == 0 ? multA : multB;
-    if (blocksFrom) G = max(1u, (*blocksFrom + B - 1u) / B);
+    if (blocksFrom) G = max(1u, QSEG * segq_nee_rows(*blocksFrom, B));
     const uint32_t l = threadIdx.x;
     const uint32_t c = q.ctl[SEGQ_COUNT + l * QSTRIDE];
     uint32_t x = c;   // inclusive scan over the 64 segments
@@ -26,7 +26,7 @@ __global__ void segq_scan_kernel(SegQ qa, uint32_t Ga, uint32_t Ba, uint32_t mul
         q.ctl[SEGQ_PREFIX + QSEG] = x;
         totals[blockIdx.x == 0 ? slotA : slotB] = x;
     }
-    q.ctl[SEGQ_START + l] = segq_first_block(l, G) * B * mult;
+    q.ctl[SEGQ_START + l] = segq_first_block(l, G, q.run) * B * mult;
     q.ctl[SEGQ_COUNT + l * QSTRIDE] = 0u;
     q.ctl[SEGQ_CURSOR + l * QSTRIDE] = 0u;
 }

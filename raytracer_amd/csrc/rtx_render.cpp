@@ -129,13 +129,14 @@ static int ensure_pool(rtx_scene* s, uint32_t slots, size_t framePixels, size_t 
     const size_t qcap = (((size_t)slots + 255) / 256) * 256;
     PA(queueA, qcap);
     PA(queueB, qcap);
-    PA(shadowQ, 2 * (size_t)nL * qcap);
+    PA(shadowQ, 2 * ((size_t)nL * qcap + (size_t)QSEG * 256));   // (regions by the blocks of nee_kernel's grid, rounded up to QSEG rows)
     PA(neeCtx, 8 * qcap);   // NEE_CTX_VEC float4 per vertex of a bounce (nee_ctx.h)
     d.neeStride = qcap;
     PA(qA.ctl, SEGQ_WORDS);
     PA(qB.ctl, SEGQ_WORDS);
     PA(qS.ctl, SEGQ_WORDS);
     PA(qN.ctl, SEGQ_WORDS);
+    d.qN.run = 4u;   // shade_kernel's waves reserve their pairs one atomic each: interleaved segments (segqueue.h; nee_kernel reads them transposed)
     PA(neeQ, 2 * (size_t)nL * qcap);
     PA(totals, 16);
     PA(cullPaths, RTX_CULL_CAP);

@@ -22,23 +22,24 @@
 
 struct SegQ {
     uint32_t* ctl;        // SEGQ_WORDS control words (layout above)
+    uint32_t run = 0u;    // 0: contiguous segments; K: producer blocks go round the segments in runs of K (segq_segment_of_block)
 };
 
-// Segment of producer block b in a grid of G blocks, and the first block of segment s.
-#ifdef SEGQ_RUN
-__host__ __device__ inline uint32_t segq_segment_of_block(uint32_t b, uint32_t G) { return (b / SEGQ_RUN) % QSEG; }
-__host__ __device__ inline uint32_t segq_first_block(uint32_t s, uint32_t G) {   // blocks of the segments before s
-    const uint32_t runs = G / SEGQ_RUN, rem = G % SEGQ_RUN, r = runs % QSEG;      // full runs; blocks of the last, partial run (of segment r)
-    return SEGQ_RUN * (s * (runs / QSEG) + (s < r ? s : r)) + (r < s ? rem : 0u);
-}
-#else
-__host__ __device__ inline uint32_t segq_segment_of_block(uint32_t b, uint32_t G) {
+// Segment of producer block b in a grid of G blocks, and the number of blocks in the segments before s (the first block of a
+// contiguous segment). run = 0: segment s holds the blocks [s G / 64, (s + 1) G / 64): the queue keeps the producers' order.
+// run = K > 0: the blocks go round the segments in runs of K - the blocks in flight at one time, whose indices are neighbours,
+// then append through 64 counters instead of one or two (SegQ::run).
+__host__ __device__ inline uint32_t segq_segment_of_block(uint32_t b, uint32_t G, uint32_t run = 0u) {
+    if (run) return (b / run) % QSEG;
     return (uint32_t)(((unsigned long long)b * QSEG) / G);
 }
-__host__ __device__ inline uint32_t segq_first_block(uint32_t s, uint32_t G) {
+__host__ __device__ inline uint32_t segq_first_block(uint32_t s, uint32_t G, uint32_t run = 0u) {
+    if (run) {
+        const uint32_t runs = G / run, rem = G % run, r = runs % QSEG;   // full runs; blocks of the last, partial run (of segment r)
+        return run * (s * (runs / QSEG) + (s < r ? s : r)) + (r < s ? rem : 0u);
+    }
     return (uint32_t)(((unsigned long long)s * G + QSEG - 1u) / QSEG);
 }
-#endif
 
 #ifdef __HIPCC__
 // Producer side: every lane of the wave calls this (pred = lane has an entry); returns the item index to write.
@@ -49,7 +50,7 @@ __host__ __device__ inline uint32_t segq_first_block(uint32_t s, uint32_t G) {
 __device__ __forceinline__ uint32_t segq_append_g(const SegQ& q, bool pred, uint32_t mult, uint32_t G);
 __device__ __forceinline__ uint32_t segq_append(const SegQ& q, bool pred, uint32_t mult) { return segq_append_g(q, pred, mult, gridDim.x); }
 __device__ __forceinline__ uint32_t segq_append_g(const SegQ& q, bool pred, uint32_t mult, uint32_t G) {
-    const uint32_t seg = segq_segment_of_block(blockIdx.x, G);
+    const uint32_t seg = segq_segment_of_block(blockIdx.x, G, q.run);
     const unsigned long long mask = __ballot(pred);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = (uint32_t)__popcll(mask);
@@ -60,7 +61,7 @@ __device__ __forceinline__ uint32_t segq_append_g(const SegQ& q, bool pred, uint
         base = __shfl(base, leader);
     }
     const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    return segq_first_block(seg, G) * blockDim.x * mult + base + prefix;
+    return segq_first_block(seg, G, q.run) * blockDim.x * mult + base + prefix;
 }
 
 // The same with one atomic per BLOCK: every thread of the block calls it, outside divergent control flow (two barriers). The
@@ -68,7 +69,7 @@ __device__ __forceinline__ uint32_t segq_append_g(const SegQ& q, bool pred, uint
 // up at one address after all; a block of four waves asks a quarter as often. tmp: SEGQ_BLOCK_WORDS words of LDS.
 #define SEGQ_BLOCK_WORDS 20u   // [0] base, [1] block total, [2 + w] entries of wave w (blocks of up to 16 waves)
 __device__ __forceinline__ uint32_t segq_append_block(const SegQ& q, bool pred, uint32_t mult, uint32_t G, uint32_t* tmp) {
-    const uint32_t seg = segq_segment_of_block(blockIdx.x, G);
+    const uint32_t seg = segq_segment_of_block(blockIdx.x, G, q.run);
     const unsigned long long mask = __ballot(pred);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nWaves = (blockDim.x + 63u) >> 6;
     if (lane == 0) tmp[2u + wave] = (uint32_t)__popcll(mask);
@@ -82,20 +83,20 @@ __device__ __forceinline__ uint32_t segq_append_block(const SegQ& q, bool pred, 
     uint32_t before = 0;
     for (uint32_t w = 0; w < wave; ++w) before += tmp[2u + w];
     const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    return segq_first_block(seg, G) * blockDim.x * mult + tmp[0] + before + prefix;
+    return segq_first_block(seg, G, q.run) * blockDim.x * mult + tmp[0] + before + prefix;
 }
 
 // The same for a wave that appends `total` entries at once (wave-uniform, > 0; every active lane calls): returns the item
 // index of the first; the caller hands out [first, first + total) among its lanes.
 __device__ __forceinline__ uint32_t segq_reserve(const SegQ& q, uint32_t total, uint32_t mult) {
-    const uint32_t seg = segq_segment_of_block(blockIdx.x, gridDim.x);
+    const uint32_t seg = segq_segment_of_block(blockIdx.x, gridDim.x, q.run);
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long mask = __ballot(true);
     const int leader = __ffsll((long long)mask) - 1;
     uint32_t base = 0;
     if ((int)lane == leader) base = atomicAdd(&q.ctl[SEGQ_COUNT + seg * QSTRIDE], total);
     base = __shfl(base, leader);
-    return segq_first_block(seg, gridDim.x) * blockDim.x * mult + base;
+    return segq_first_block(seg, gridDim.x, q.run) * blockDim.x * mult + base;
 }
 
 // Flat consumer: item index of entry i (i < total). tab = LDS copy of prefix[QSEG+1] followed by start[QSEG],
@@ -124,54 +125,6 @@ __device__ __forceinline__ uint32_t segq_home(uint32_t wave) { return (wave % SE
 // Persistent consumer. All fields are wave-uniform. A wave reserves `chunk` consecutive entries of its current
 // segment with one atomic and hands them to its lanes over several refills, so most refills cost no atomic round
 // trip (during which the wave's busy lanes would stall too).
-#ifdef SEGQ_RUN
-// Interleaved segments (SEGQ_RUN): the blocks of a producer grid go round the segments in runs, so entry k of every segment comes
-// from about the same place in the producers' order. Consumers therefore take chunk c of the queue = chunk c / QSEG of segment
-// c % QSEG, through ONE cursor (a consumer wave reserves hundreds of entries per atomic: a launch makes a few ten thousand), and
-// the waves in flight work on neighbouring stretches of every segment - the producers' order, as with contiguous segments.
-struct SegWalk {
-    uint32_t resBase, resEnd;  // reserved, not yet handed out ITEM indices [resBase, resEnd)
-    uint32_t chunk;            // entries reserved per atomic (multiple of 64)
-    uint32_t limit;            // chunks of the queue: QSEG x chunks of the longest segment
-    uint32_t next;             // this wave's next chunk: its own index at first (no atomic), then from the cursor
-    uint32_t nWaves;
-};
-__device__ __forceinline__ void segq_walk_init(const SegQ& q, SegWalk& w, uint32_t wave, uint32_t chunk) {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t c = q.ctl[SEGQ_PREFIX + lane + 1u] - q.ctl[SEGQ_PREFIX + lane];
-    for (uint32_t d = 32u; d > 0u; d >>= 1) c = max(c, (uint32_t)__shfl_xor((int)c, (int)d));
-    w.chunk = chunk;
-    w.limit = QSEG * ((__builtin_amdgcn_readfirstlane(c) + chunk - 1u) / chunk);
-    w.resBase = w.resEnd = 0u;
-    w.next = wave;
-    w.nWaves = (gridDim.x * blockDim.x) >> 6;
-}
-__device__ __forceinline__ uint32_t segq_take(const SegQ& q, SegWalk& w, uint32_t want, uint32_t& first) {
-    const uint32_t lane = threadIdx.x & 63u;
-    for (;;) {
-        if (w.resBase < w.resEnd) {
-            const uint32_t g = min(want, w.resEnd - w.resBase);
-            first = w.resBase;
-            w.resBase += g;
-            return g;
-        }
-        if (w.next >= w.limit) return 0u;
-        const uint32_t c = w.next;
-        {   // the chunk after this one: from the shared cursor, which counts the chunks beyond the waves' first ones
-            uint32_t t = 0;
-            if (lane == 0) t = atomicAdd(&q.ctl[SEGQ_CURSOR], 1u);
-            w.next = w.nWaves + __builtin_amdgcn_readfirstlane(t);
-        }
-        const uint32_t seg = c % QSEG, off = (c / QSEG) * w.chunk;
-        const uint32_t cnt = __builtin_amdgcn_readfirstlane(q.ctl[SEGQ_PREFIX + seg + 1u] - q.ctl[SEGQ_PREFIX + seg]);
-        if (off < cnt) {
-            const uint32_t start = __builtin_amdgcn_readfirstlane(q.ctl[SEGQ_START + seg]);
-            w.resBase = start + off;
-            w.resEnd = start + min(cnt, off + w.chunk);
-        }
-    }
-}
-#else
 struct SegWalk {
     uint32_t seg;              // current segment
     uint32_t cnt, start;       // its entry count and first item index
@@ -221,15 +174,19 @@ __device__ __forceinline__ uint32_t segq_take(const SegQ& q, SegWalk& w, uint32_
     }
 }
 #endif
-#endif
 
 // Host-callable wrappers (kernels_trace.hip)
 // counts -> prefix/start/total for a queue produced by a grid of G blocks of B threads appending <= mult entries per
 // thread; zeroes the counters and cursors; totals[slot] = number of entries.
 // blocksFrom (optional): a queue total on the device; the producer grid then counts ceil(*blocksFrom / blockThreads) blocks
 // (a producer launched over an upper bound that lays its regions out by the true count: nee_kernel)
+// blocksFrom: the producer is nee_kernel, which runs its blocks in a permuted order over a grid rounded up to QSEG rows
+// (segq_nee_rows): G = that grid
 void launch_segq_scan(const SegQ& q, uint32_t producerBlocks, uint32_t blockThreads, uint32_t mult, uint32_t* totals,
                       uint32_t totalsSlot, hipStream_t stream, const uint32_t* blocksFrom = nullptr);
+// nee_kernel's grid for `total` queued pairs in blocks of B threads: QSEG x rows blocks, block j works on the flat chunk
+// (j % QSEG) * rows + j / QSEG (kernels_nee.hip)
+__host__ __device__ inline uint32_t segq_nee_rows(uint32_t total, uint32_t B) { return ((total + B - 1u) / B + QSEG - 1u) / QSEG; }
 // identity queue over [0, n): segment s covers [s*n/QSEG, (s+1)*n/QSEG)
 void launch_segq_identity(const SegQ& q, uint32_t n, hipStream_t stream);
 // entries a persistent consumer wave reserves per atomic, for n entries drained by `waves` waves
