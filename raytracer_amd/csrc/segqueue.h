@@ -118,7 +118,13 @@ __device__ __forceinline__ uint32_t segq_item_index(const uint32_t* tab, uint32_
 // forward from there: enough distinct counters to keep the atomics off one address, few enough active regions that
 // the waves running at the same time work on neighbouring rays (which share BVH nodes in L2).
 #ifndef SEGQ_GROUPS
-#define SEGQ_GROUPS 16u
+#define SEGQ_GROUPS 32u
+#endif
+#ifndef SEGQ_CHUNK_MAX
+#define SEGQ_CHUNK_MAX 512ull
+#endif
+#ifndef SEGQ_CHUNK_DIV
+#define SEGQ_CHUNK_DIV 8ull
 #endif
 __device__ __forceinline__ uint32_t segq_home(uint32_t wave) { return (wave % SEGQ_GROUPS) * (QSEG / SEGQ_GROUPS); }
 
@@ -191,7 +197,7 @@ __host__ __device__ inline uint32_t segq_nee_rows(uint32_t total, uint32_t B) { 
 void launch_segq_identity(const SegQ& q, uint32_t n, hipStream_t stream);
 // entries a persistent consumer wave reserves per atomic, for n entries drained by `waves` waves
 inline uint32_t segq_chunk(uint32_t n, uint32_t waves) {
-    unsigned long long c = (unsigned long long)n / ((unsigned long long)(waves ? waves : 1u) * 8ull);
+    unsigned long long c = (unsigned long long)n / ((unsigned long long)(waves ? waves : 1u) * SEGQ_CHUNK_DIV);
     c = (c / 64ull) * 64ull;
-    return (uint32_t)(c < 64ull ? 64ull : (c > 1024ull ? 1024ull : c));
+    return (uint32_t)(c < 64ull ? 64ull : (c > SEGQ_CHUNK_MAX ? SEGQ_CHUNK_MAX : c));
 }
