@@ -260,7 +260,7 @@ __device__ __forceinline__ uint32_t blocker_key(const DevScene& sc, const PathPo
 // gives the bench the algorithmic bytes of a shadow hop (48 + nodes x 64 + triangles x 48)
 // (the general kernel runs best at four waves per SIMD - 4 / 5 / 6: 64 / 85 / 134 ms on the C3 scene forced through it - and sits
 // right at that register limit: it is told to stay there; the lean kernels are left to the compiler: 78-91 registers, five or six waves)
-template <bool XF, bool CULL = false, bool COUNT = false>
+template <bool XF, bool CULL = false, bool COUNT = false, bool FRONT = false>
 #ifdef SHADOW_WAVES_PER_EU
 __attribute__((amdgpu_waves_per_eu(SHADOW_WAVES_PER_EU)))
 #else
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
     s.sp = 0;
     bool exhausted = false;
     SegWalk walk;
-    segq_walk_init(q, walk, gtid >> 6, chunk);
+    segq_walk_init<FRONT>(q, walk, gtid >> 6, chunk);
     uint32_t code = 0, entry = 0;
     f3 o = mk3(0.0f), d = mk3(0.0f);
     float maxDist = 0.0f, visibility = 1.0f;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) void shadow_kernel(DevScene scArg, Path
         const uint32_t nIdle = (uint32_t)__popcll(idle);
         if (!exhausted && nIdle >= SHADOW_REFILL_MIN) {
             uint32_t first = 0;
-            const uint32_t got = segq_take(q, walk, nIdle, first);
+            const uint32_t got = segq_take<FRONT>(q, walk, nIdle, first);
             if (got == 0u) exhausted = true;
             if (s.cur == RTX_LANE_IDLE) {
                 const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
@@ -698,6 +698,15 @@ void launch_shadow(const DevScene& sc, const LaunchCfg& cfg, const PathPool& poo
 #define RTX_LAUNCH_SHADOW(X, C, N)                                                                                                          \
     hipLaunchKernelGGL((shadow_kernel<X, C, N>), dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, pool, q, useTransmittance, cfg.spill,     \
                        segq_chunk(n, grid * (TRAV_BLOCK / 64)), (const uint32_t*)nullptr, cfg.counters)
+#define RTX_LAUNCH_SHADOW_FRONT(X, C)                                                                                                       \
+    hipLaunchKernelGGL((shadow_kernel<X, C, false, true>), dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, pool, q, useTransmittance,      \
+                       cfg.spill, segq_chunk(n, grid * (TRAV_BLOCK / 64)), (const uint32_t*)nullptr, cfg.counters)
+    if (!cfg.counting && segq_front(n)) {   // a launch of middling size walks its queue as one front (segqueue.h SegWalk)
+        if (sc.has_xf) RTX_LAUNCH_SHADOW_FRONT(true, false);
+        else if (pool.cullShadows) RTX_LAUNCH_SHADOW_FRONT(false, true);
+        else RTX_LAUNCH_SHADOW_FRONT(false, false);
+        return;
+    }
     if (sc.has_xf) {
         if (cfg.counting) RTX_LAUNCH_SHADOW(true, false, true);
         else RTX_LAUNCH_SHADOW(true, false, false);
@@ -708,6 +717,7 @@ void launch_shadow(const DevScene& sc, const LaunchCfg& cfg, const PathPool& poo
     else
         RTX_LAUNCH_SHADOW(false, false, false);
 #undef RTX_LAUNCH_SHADOW
+#undef RTX_LAUNCH_SHADOW_FRONT
 }
 // The chains the lean shadow kernel set aside (pool.cullShadows, their number in pool.totals[5]) through the general
 // kernel. The host does not know the number: a one-wave kernel turns it into an identity queue over the list and resets it,

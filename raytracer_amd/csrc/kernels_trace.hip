@@ -77,7 +77,7 @@ void launch_segq_identity(const SegQ& q, uint32_t n, hipStream_t stream) {
 #endif
 // BOTH: hitSide is RTX_HIT_FRONT_AND_BACK (every ray of the render loop): the side test of objects.cpp:175-191 - a normalised
 // geometric normal per candidate - is then not compiled into the leaf step (19 ms of the C3 frame's extend time)
-template <bool COUNT, bool XF, bool BOTH>
+template <bool COUNT, bool XF, bool BOTH, bool FRONT = false>
 __global__ __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(XF ? EXTEND_WAVES_PER_EU_GENERAL : EXTEND_WAVES_PER_EU))) void extend_kernel(DevScene scArg, const float4* __restrict__ rays, SegQ q,
                                                             const uint32_t* __restrict__ items, int hitSide, int withLights,
                                                             float4* __restrict__ hits, uint2* spill, unsigned long long* counters,
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(XF ?
     s.sp = 0;
     bool exhausted = false;   // the queue is drained (wave-uniform)
     SegWalk walk;
-    segq_walk_init(q, walk, gtid >> 6, chunk);
+    segq_walk_init<FRONT>(q, walk, gtid >> 6, chunk);
     uint32_t rayIndex = 0;
     for (;;) {
         // ---- retire finished rays in batches (a handful of lanes running the epilogue every iteration would cost
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(XF ?
         const uint32_t nIdle = (uint32_t)__popcll(idle);
         if (!exhausted && nIdle >= REFILL_MIN) {
             uint32_t first = 0;
-            const uint32_t got = segq_take(q, walk, nIdle, first);
+            const uint32_t got = segq_take<FRONT>(q, walk, nIdle, first);
             if (got == 0u) exhausted = true;
             if (s.cur == RTX_LANE_IDLE) {
                 const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
@@ -173,6 +173,18 @@ void launch_extend_queue(const DevScene& sc, const LaunchCfg& cfg, const float4*
 #define RTX_LAUNCH_EXTEND(C, X, B)                                                                                                  \
     hipLaunchKernelGGL((extend_kernel<C, X, B>), dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, rays, q, items, hitSide, withLights, \
                        hits, cfg.spill, cfg.counters, chunk)
+#define RTX_LAUNCH_EXTEND_FRONT(X, B)                                                                                                     \
+    hipLaunchKernelGGL((extend_kernel<false, X, B, true>), dim3(grid), dim3(TRAV_BLOCK), 0, cfg.stream, sc, rays, q, items, hitSide, withLights, \
+                       hits, cfg.spill, cfg.counters, chunk)
+    if (!cfg.counting && segq_front(n)) {   // a launch of middling size walks its queue as one front (segqueue.h SegWalk)
+        switch ((sc.has_xf ? 2 : 0) | (hitSide == RTX_HIT_FRONT_AND_BACK ? 1 : 0)) {
+            case 0: RTX_LAUNCH_EXTEND_FRONT(false, false); break;
+            case 1: RTX_LAUNCH_EXTEND_FRONT(false, true); break;
+            case 2: RTX_LAUNCH_EXTEND_FRONT(true, false); break;
+            default: RTX_LAUNCH_EXTEND_FRONT(true, true); break;
+        }
+        return;
+    }
     switch ((cfg.counting ? 4 : 0) | (sc.has_xf ? 2 : 0) | (hitSide == RTX_HIT_FRONT_AND_BACK ? 1 : 0)) {
         case 0: RTX_LAUNCH_EXTEND(false, false, false); break;
         case 1: RTX_LAUNCH_EXTEND(false, false, true); break;
@@ -184,6 +196,7 @@ void launch_extend_queue(const DevScene& sc, const LaunchCfg& cfg, const float4*
         default: RTX_LAUNCH_EXTEND(true, true, true); break;
     }
 #undef RTX_LAUNCH_EXTEND
+#undef RTX_LAUNCH_EXTEND_FRONT
 }
 void launch_extend(const DevScene& sc, const LaunchCfg& cfg, const float4* rays, uint32_t n, int hitSide, int withLights,
                    float4* hits) {
