@@ -479,7 +479,9 @@ int rtx_get_counters(rtx_scene* scene, uint64_t out[3]);
  * with weight > 0, -1 otherwise. The same rule as raytracer_amd/distributed.py::lpt_assign.
  * rtx_debug_queue_layout: geometry of the segmented ray queues (csrc/segqueue.h) for a producer grid of
  * `producer_blocks` blocks of `block_threads` threads appending at most `mult` entries per thread: start[s] = first
- * item index of segment s (64 segments), segment_of_block[b] for every block (array of producer_blocks). */
+ * item index of segment s (64 segments), segment_of_block[b] for every block (array of producer_blocks).
+ * rtx_debug_queue_layout_run: the same for a queue whose producer blocks go round the segments in runs of `run` blocks
+ * (SegQ::run, the pair queue between shade_kernel and nee_kernel; run = 0: contiguous segments, as above). */
 int rtx_debug_validate_bvh(const rtx_scene_desc* desc, uint64_t out[3]);
 /* A host model of the kernels' traversal order (no device needed): flattens desc, walks n rays {o, tmax, d} to their closest
  * hit among the world-space triangles in the order the kernels visit the tree, and returns t_out[i] (-1 = miss), prim_out[i]
@@ -495,6 +497,8 @@ int rtx_debug_host_walk(const rtx_scene_desc* desc, const rtx_ray* rays, size_t 
 int rtx_debug_math(int fn, const float* x, const float* y, size_t n, float* out, int on_device);
 int rtx_debug_queue_layout(uint32_t producer_blocks, uint32_t block_threads, uint32_t mult, uint32_t start[64],
                            uint32_t* segment_of_block);
+int rtx_debug_queue_layout_run(uint32_t producer_blocks, uint32_t block_threads, uint32_t mult, uint32_t run, uint32_t start[64],
+                               uint32_t* segment_of_block);
 int64_t rtx_debug_pixel_list(int width, int height, int tile, int rank, int world, int* out, size_t capacity);
 int rtx_debug_lpt_assign(const int* weight, size_t n_buckets, int members, int* owner);
 

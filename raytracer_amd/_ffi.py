@@ -188,6 +188,7 @@ SYMBOLS = [
     ("rtx_debug_host_walk", C.c_int, [C.POINTER(SceneDesc), _vp, C.c_size_t, _vp, _vp, C.POINTER(C.c_uint64)]),
     ("rtx_debug_math", C.c_int, [C.c_int, _vp, _vp, C.c_size_t, _vp, C.c_int]),
     ("rtx_debug_queue_layout", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("rtx_debug_queue_layout_run", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("rtx_debug_pixel_list", C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t]),
     ("rtx_debug_lpt_assign", C.c_int, [_vp, C.c_size_t, C.c_int, _vp]),
 ]

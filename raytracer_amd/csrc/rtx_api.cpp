@@ -334,13 +334,17 @@ int rtx_debug_host_walk(const rtx_scene_desc* desc, const rtx_ray* rays, size_t 
     return RTX_OK;
 }
 
+int rtx_debug_queue_layout_run(uint32_t producer_blocks, uint32_t block_threads, uint32_t mult, uint32_t run, uint32_t start[64],
+                               uint32_t* segment_of_block) {
+    if (!producer_blocks || !block_threads || !mult || !start) return rtx_fail(RTX_ERR_INVALID, "bad argument");
+    for (uint32_t s = 0; s < QSEG; ++s) start[s] = segq_first_block(s, producer_blocks, run) * block_threads * mult;
+    if (segment_of_block)
+        for (uint32_t b = 0; b < producer_blocks; ++b) segment_of_block[b] = segq_segment_of_block(b, producer_blocks, run);
+    return RTX_OK;
+}
 int rtx_debug_queue_layout(uint32_t producer_blocks, uint32_t block_threads, uint32_t mult, uint32_t start[64],
                            uint32_t* segment_of_block) {
-    if (!producer_blocks || !block_threads || !mult || !start) return rtx_fail(RTX_ERR_INVALID, "bad argument");
-    for (uint32_t s = 0; s < QSEG; ++s) start[s] = segq_first_block(s, producer_blocks) * block_threads * mult;
-    if (segment_of_block)
-        for (uint32_t b = 0; b < producer_blocks; ++b) segment_of_block[b] = segq_segment_of_block(b, producer_blocks);
-    return RTX_OK;
+    return rtx_debug_queue_layout_run(producer_blocks, block_threads, mult, 0u, start, segment_of_block);
 }
 
 int rtx_debug_math(int fn, const float* x, const float* y, size_t n, float* out, int on_device) {

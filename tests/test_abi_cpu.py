@@ -167,3 +167,29 @@ def test_segmented_queue_layout(blocks, mult):
         first[seg[b]] = b
     used = first >= 0
     assert (start[used] == first[used] * 256 * mult).all()
+
+
+@pytest.mark.parametrize("blocks", [1, 3, 4, 5, 255, 256, 257, 1000, 260001])
+@pytest.mark.parametrize("run", [1, 4, 16])
+def test_interleaved_queue_layout(blocks, run):
+    """csrc/segqueue.h, SegQ::run (the pair queue between shade_kernel and nee_kernel): producer blocks go round the 64
+    segments in runs of `run` blocks. Whatever the grid, the segments' regions must tile the queue's capacity exactly - each
+    as large as everything its blocks can append - and neighbouring runs must land in different segments."""
+    import ctypes as C
+    lib = _ffi.load_library()
+    mult = 3
+    start = (C.c_uint32 * 64)()
+    seg = (C.c_uint32 * blocks)()
+    assert lib.rtx_debug_queue_layout_run(blocks, 256, mult, run, start, seg) == 0
+    start = np.array(start[:], np.int64)
+    seg = np.array(seg[:], np.int64)
+    assert seg.min() >= 0 and seg.max() <= 63
+    assert (seg == (np.arange(blocks) // run) % 64).all()
+    per_seg = np.bincount(seg, minlength=64) * 256 * mult
+    assert start[0] == 0 and (start[1:] == np.cumsum(per_seg)[:-1]).all()      # dense: no gap, no overlap
+    assert start[-1] + per_seg[-1] == blocks * 256 * mult
+    # run = 0 is the contiguous layout of rtx_debug_queue_layout
+    a = (C.c_uint32 * 64)()
+    b = (C.c_uint32 * 64)()
+    assert lib.rtx_debug_queue_layout_run(blocks, 256, mult, 0, a, None) == 0 and lib.rtx_debug_queue_layout(blocks, 256, mult, b, None) == 0
+    assert a[:] == b[:]
