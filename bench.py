@@ -421,7 +421,8 @@ class Measured:
         if not ks:
             return None, 0
         # 2 x FETCH_SIZE: gfx950 tallies 128-B requests at 64 B (MI355X_MICROARCH.md "HBM")
-        return sum((2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 for k in ks), max(k["dispatches"] for k in ks)
+        # (the instantiations a prefix names - by-segment and front walk, plain and REPACK - are launches of the same kernel)
+        return sum((2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0 for k in ks), sum(k["dispatches"] for k in ks)
 
     def traffic(self, *prefixes):          # bytes per frame (the PMC pass runs one frame)
         return self._sum(prefixes)[0]
@@ -433,7 +434,11 @@ class Measured:
     def limiter(self, prefix):
         if not self.l:
             return None
-        k = next((v for n, v in self.l.items() if n.startswith(prefix)), None)
+        # the instantiation that carries the full-size frame: the by-segment walk / the bounce without compaction (last template
+        # argument false); the counter pass runs a small frame, whose launches mostly take the front walk
+        ks = [(n, v) for n, v in self.l.items() if n.startswith(prefix)]
+        main = [v for n, v in ks if n.endswith("false>")]
+        k = main[0] if main else (max((v for _, v in ks), key=lambda v: v.get("waves", 0.0)) if ks else None)
         return dict(k, source=self.limiter_src) if k else None
 
 
