@@ -118,6 +118,10 @@ __device__ __forceinline__ uint32_t segq_item_index(const uint32_t* tab, uint32_
 // First segment of a persistent consumer wave. Waves start in SEGQ_GROUPS groups spread over the queue and walk
 // forward from there: enough distinct counters to keep the atomics off one address, few enough active regions that
 // the waves running at the same time work on neighbouring rays (which share BVH nodes in L2).
+// (re-tuned in round 3, once the producers appended per block - C3 frame, extend / shadow ms: 4 groups 313 / 178, 8: 295 / 161,
+// 16: 287.5 / 152.7, 32: 283.7 / 149.4, 64: 285 / 150; then reservations of at most 2048 / 1024 / 512 / 256 entries with 32
+// groups: extend 290 / 285 / 281 / 281, shadow 152 / 150.3 / 148.3 / 150.4. The waves' waits at the cursors are what the
+// smaller groups and reservations save; 48 groups, which do not divide the segments evenly: 306 / 174.)
 #ifndef SEGQ_GROUPS
 #define SEGQ_GROUPS 32u
 #endif
