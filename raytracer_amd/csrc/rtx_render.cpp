@@ -14,6 +14,13 @@
 struct PathPoolHost {
     PathPool dev{};
     std::vector<void*> allocs;
+    // The arrays of the pool proper are carved from ONE allocation (ensure_pool): slabPhase 1 adds their sizes up, 2 hands the
+    // pieces out, 0 (arrays allocated later: legacy state, side spill slab) is a hipMalloc each. With an allocation per array
+    // nee_kernel took 35 or 41 ms per C3 frame depending on the process - where the driver happened to put its four streams -
+    // and 41 in the first process on a fresh machine; from one allocation it takes 37 in every process.
+    char* slab = nullptr;
+    size_t slabNeed = 0, slabUsed = 0;
+    int slabPhase = 0;
     uint32_t capacity = 0;        // slots of a pass
     uint32_t extra = 0;           // slots of the compaction area behind them (pathstate.h "Compaction")
     int nLights = 0;
@@ -74,6 +81,17 @@ template <class T>
 static int pool_alloc(PathPoolHost* ph, T** out, size_t count) {
     void* p = nullptr;
     size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    if (ph->slabPhase) {
+        const size_t piece = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);   // 2 MB pieces
+        if (ph->slabPhase == 1) {
+            ph->slabNeed += piece;
+            *out = nullptr;
+        } else {
+            *out = (T*)(ph->slab + ph->slabUsed);
+            ph->slabUsed += piece;
+        }
+        return RTX_OK;
+    }
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) return rtx_fail(RTX_ERR_HIP, std::string("path pool hipMalloc: ") + hipGetErrorString(e));
     ph->allocs.push_back(p);
@@ -110,6 +128,7 @@ static int ensure_pool(rtx_scene* s, uint32_t slots, size_t framePixels, size_t 
     d.capacity = (uint32_t)all;
     d.baseCap = slots;   // (render_impl sets it for each pass)
     int rc;
+    auto layout = [&]() -> int {
 #define PA(field, count) \
     if ((rc = pool_alloc(ph, &d.field, (count))) != RTX_OK) return rc;
     PA(rays, 2 * all);
@@ -158,7 +177,7 @@ static int ensure_pool(rtx_scene* s, uint32_t slots, size_t framePixels, size_t 
                 d.blockerMask = (1u << 22) - 1u;
                 d.blockerScale = (float)cells / ext;
                 PA(blockerCache, (size_t)d.blockerMask + 1);
-                if (hipMemset(d.blockerCache, 0xFF, ((size_t)d.blockerMask + 1) * sizeof(int)) != hipSuccess) return rtx_fail(RTX_ERR_HIP, "blocker cache clear failed");
+                if (ph->slabPhase != 1 && hipMemset(d.blockerCache, 0xFF, ((size_t)d.blockerMask + 1) * sizeof(int)) != hipSuccess) return rtx_fail(RTX_ERR_HIP, "blocker cache clear failed");
             }
         }
     }
@@ -170,6 +189,27 @@ static int ensure_pool(rtx_scene* s, uint32_t slots, size_t framePixels, size_t 
     PA(rayCounters, 8);
 #undef PA
     return RTX_OK;
+    };
+    ph->slabPhase = 1;
+    ph->slabNeed = 0;
+    rc = layout();
+    if (rc == RTX_OK) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, ph->slabNeed);
+        if (e == hipSuccess) {
+            ph->allocs.push_back(p);
+            ph->bytes += ph->slabNeed;
+            ph->slab = (char*)p;
+            ph->slabUsed = 0;
+            ph->slabPhase = 2;
+        } else {
+            (void)hipGetLastError();   // no piece of that size: an allocation per array, as before round 3
+            ph->slabPhase = 0;
+        }
+        rc = layout();
+    }
+    ph->slabPhase = 0;
+    return rc;
 }
 
 // Pixel list of the buckets owned by (rank, world): RayCaster.cpp:1152-1158 builds 16x16 buckets row-major; bucket b
