@@ -195,7 +195,8 @@ static int ensure_pool(rtx_scene* s, uint32_t slots, size_t framePixels, size_t 
     rc = layout();
     if (rc == RTX_OK) {
         void* p = nullptr;
-        hipError_t e = hipMalloc(&p, ph->slabNeed);
+        const char* sw = std::getenv("RTX_AMD_POOL_SLAB");   // =0: an allocation per array (the fallback below, for the tests)
+        hipError_t e = (sw && std::atoi(sw) == 0) ? hipErrorOutOfMemory : hipMalloc(&p, ph->slabNeed);
         if (e == hipSuccess) {
             ph->allocs.push_back(p);
             ph->bytes += ph->slabNeed;

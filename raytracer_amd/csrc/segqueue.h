@@ -239,9 +239,10 @@ __host__ __device__ inline uint32_t segq_nee_rows(uint32_t total, uint32_t B) { 
 void launch_segq_identity(const SegQ& q, uint32_t n, hipStream_t stream);
 // whether a launch over n entries walks its queue as one front (SegWalk); RTX_AMD_FRONT_MIN / _MAX move the limits
 inline bool segq_front(uint32_t n) {
-    static const long lo = std::getenv("RTX_AMD_FRONT_MIN") ? std::atol(std::getenv("RTX_AMD_FRONT_MIN")) : 230000L;
-    static const long hi = std::getenv("RTX_AMD_FRONT_MAX") ? std::atol(std::getenv("RTX_AMD_FRONT_MAX")) : 5500000L;
-    return (long)n >= lo && (long)n <= hi;
+    const char* a = std::getenv("RTX_AMD_FRONT_MIN");   // (read per launch: the tests switch them between renders)
+    const char* b = std::getenv("RTX_AMD_FRONT_MAX");
+    const long long lo = a ? std::atoll(a) : 230000LL, hi = b ? std::atoll(b) : 5500000LL;
+    return (long long)n >= lo && (long long)n <= hi;
 }
 // entries a persistent consumer wave reserves per atomic, for n entries drained by `waves` waves
 inline uint32_t segq_chunk(uint32_t n, uint32_t waves) {

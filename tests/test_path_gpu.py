@@ -200,6 +200,22 @@ def test_scheduling_switches_do_not_change_results(small, monkeypatch):
     fixed, st4 = gs.render_samples(cam, rp)
     monkeypatch.delenv("RTX_AMD_REPACK")
     assert st4["repacks"] == 0 and np.array_equal(fixed, base)
+    # the persistent kernels' walk of their queue (segqueue.h SegWalk): every extend / shadow launch as one front, or none
+    monkeypatch.setenv("RTX_AMD_FRONT_MIN", "0")
+    monkeypatch.setenv("RTX_AMD_FRONT_MAX", "4000000000")
+    front, st5 = gs.render_samples(cam, rp)
+    monkeypatch.setenv("RTX_AMD_FRONT_MAX", "0")
+    by_segment, st6 = gs.render_samples(cam, rp)
+    monkeypatch.delenv("RTX_AMD_FRONT_MIN")
+    monkeypatch.delenv("RTX_AMD_FRONT_MAX")
+    assert np.array_equal(front, base) and np.array_equal(by_segment, base)
+    assert st5["rays_shadow"] == st0["rays_shadow"] and st6["rays_bounce"] == st0["rays_bounce"]
+    # the path pool as an allocation per array (the fallback of ensure_pool) instead of one slab: a scene of its own, since a
+    # scene keeps its pool
+    monkeypatch.setenv("RTX_AMD_POOL_SLAB", "0")
+    apart, _ = type(gs)(sd).render_samples(cam, rp)
+    monkeypatch.delenv("RTX_AMD_POOL_SLAB")
+    assert np.array_equal(apart, base)
 
 
 @pytest.mark.parametrize("mode", [_ffi.SHADING_PATH, _ffi.SHADING_LEGACY])
