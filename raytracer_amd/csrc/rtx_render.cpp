@@ -17,7 +17,7 @@ struct PathPoolHost {
     // The arrays of the pool proper are carved from ONE allocation (ensure_pool): slabPhase 1 adds their sizes up, 2 hands the
     // pieces out, 0 (arrays allocated later: legacy state, side spill slab) is a hipMalloc each. With an allocation per array
     // nee_kernel took 35 or 41 ms per C3 frame depending on the process - where the driver happened to put its four streams -
-    // and 41 in the first process on a fresh machine; from one allocation it takes 37 in every process.
+    // and 41 in the first process on a fresh machine; from one allocation it took 37 in 18 of 19 processes.
     char* slab = nullptr;
     size_t slabNeed = 0, slabUsed = 0;
     int slabPhase = 0;
